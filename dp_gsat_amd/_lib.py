@@ -1,0 +1,81 @@
+"""ctypes binding of libgsat_hip.so (the C ABI declared in include/gsat_hip.h).
+
+There is deliberately NO fallback: if the library is missing or a tensor is not a contiguous
+ROCm tensor, the call raises.  PyTorch is only used for device memory and streams.
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+from ctypes import c_char_p, c_float, c_int, c_int32, c_int64, c_size_t, c_uint64, c_void_p
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libgsat_hip.so")
+
+P, I64, I32, F32, SZ, INT, U64 = c_void_p, c_int64, c_int32, c_float, c_size_t, c_int, c_uint64
+
+# name -> (restype, argtypes); must list every symbol of include/gsat_hip.h (tests check this).
+SIGNATURES = {
+    "gsat_abi_version": (INT, []),
+    "gsat_last_error": (c_char_p, []),
+    "gsat_csr_workspace_bytes": (SZ, [I64, I64]),
+    "gsat_rev_workspace_bytes": (SZ, [I64]),
+    "gsat_build_csr": (INT, [P, P, I64, I64, P, P, P, P, P, SZ, P]),
+    "gsat_reverse_edge_perm": (INT, [P, I64, I64, P, P, P, SZ, P]),
+    "gsat_segment_ptr": (INT, [P, I64, I64, P, P, P]),
+    "gsat_gather_i64": (INT, [P, P, I64, P, P]),
+    "gsat_aggr_sum_fwd": (INT, [P, P, P, P, P, P, P, I64, I64, F32, P, P]),
+    "gsat_aggr_sum_bwd": (INT, [P, P, P, P, P, P, P, I64, I64, F32, P, P, P, P]),
+    "gsat_segment_pool_fwd": (INT, [P, P, I64, I64, INT, P, P]),
+    "gsat_segment_pool_bwd": (INT, [P, P, I64, I64, INT, P, P]),
+}
+
+_lib = None
+
+
+class GsatHipError(RuntimeError):
+    pass
+
+
+def load():
+    """Load the shared library once; raise loudly if it is not built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise GsatHipError(
+            f"{LIB_PATH} not found: the HIP extension is required (no CPU fallback). "
+            "Build it with `python -c 'import __graft_entry__ as g; g.build()'` or `make -C dp_gsat_amd/csrc`.")
+    lib = ctypes.CDLL(LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def ptr(t):
+    """Device pointer of a contiguous ROCm tensor (None -> NULL)."""
+    if t is None:
+        return None
+    if not t.is_cuda:
+        raise GsatHipError("dp_gsat_amd operators need ROCm (cuda) tensors: the HIP path has no CPU fallback")
+    if not t.is_contiguous():
+        raise GsatHipError("dp_gsat_amd operators need contiguous tensors")
+    return t.data_ptr()
+
+
+def stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def call(name, *args):
+    lib = load()
+    rc = getattr(lib, name)(*args)
+    if rc != 0:
+        msg = lib.gsat_last_error()
+        raise GsatHipError(f"{name} failed (code {rc}): {msg.decode() if msg else ''}")
+    return rc

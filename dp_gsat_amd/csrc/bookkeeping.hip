@@ -1,0 +1,212 @@
+// Integer edge bookkeeping: COO -> CSR, reverse-edge permutation, segment pointers.
+// Results are bit-exact against oracle/bookkeeping.py (stable orders everywhere).
+// One-off per batch (cached by the host), so the sort itself is rocPRIM's radix sort; the kernels
+// around it are plain coalesced integer passes.
+#include "common.h"
+#include <rocprim/rocprim.hpp>
+
+namespace gsat {
+
+static thread_local char g_err[512] = {0};
+void set_error(const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+}
+const char* get_error() { return g_err; }
+
+static int bits_for(uint64_t max_value) {   // number of low bits that can be set in [0, max_value]
+    int b = 1;
+    while (b < 64 && (max_value >> b) != 0) ++b;
+    return b;
+}
+
+__global__ void k_make_row_keys(const int64_t* __restrict__ rows, int64_t E, int64_t num_rows,
+                                uint32_t* __restrict__ keys, int32_t* __restrict__ ids, int32_t* err) {
+    int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= E) return;
+    int64_t r = rows[e];
+    if (r < 0 || r >= num_rows) { atomicAdd(err, 1); r = num_rows - 1; }
+    keys[e] = (uint32_t)r;
+    ids[e] = (int32_t)e;
+}
+
+// ptr[r] = first sorted position whose key is >= r  (r in [0, num_rows])
+template <class K>
+__global__ void k_lower_bounds(const K* __restrict__ sorted, int64_t n, int64_t num_rows, int32_t* __restrict__ ptr) {
+    int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (r > num_rows) return;
+    int64_t lo = 0, hi = n;
+    while (lo < hi) {
+        int64_t mid = (lo + hi) >> 1;
+        if ((int64_t)sorted[mid] < r) lo = mid + 1; else hi = mid;
+    }
+    ptr[r] = (int32_t)lo;
+}
+
+__global__ void k_gather_narrow(const int64_t* __restrict__ src, const int32_t* __restrict__ perm, int64_t n,
+                                int32_t* __restrict__ out) {
+    int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (k < n) out[k] = (int32_t)src[perm[k]];
+}
+
+__global__ void k_make_edge_keys(const int64_t* __restrict__ ei, int64_t E, int64_t N,
+                                 uint64_t* __restrict__ k, uint64_t* __restrict__ kt, int32_t* __restrict__ ids) {
+    int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= E) return;
+    uint64_t s = (uint64_t)ei[e], d = (uint64_t)ei[E + e];
+    k[e] = s * (uint64_t)N + d;
+    kt[e] = d * (uint64_t)N + s;
+    ids[e] = (int32_t)e;
+}
+
+__global__ void k_pair_reverse(const uint64_t* __restrict__ ks, const uint64_t* __restrict__ kts,
+                               const int32_t* __restrict__ p, const int32_t* __restrict__ q, int64_t E,
+                               int32_t* __restrict__ rev, int32_t* __restrict__ flags) {
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= E) return;
+    rev[q[i]] = p[i];
+    if (ks[i] != kts[i]) atomicAdd(&flags[1], 1);
+}
+
+__global__ void k_finish_flags(int32_t* flags) { flags[0] = flags[1] == 0 ? 1 : 0; }
+
+__global__ void k_check_sorted(const int64_t* __restrict__ ids, int64_t n, int64_t num_seg, int32_t* flags) {
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    int64_t v = ids[i];
+    bool bad = v < 0 || v >= num_seg || (i > 0 && ids[i - 1] > v);
+    if (bad) atomicAdd(flags, 1);
+}
+
+__global__ void k_gather_i64(const int64_t* __restrict__ table, const int64_t* __restrict__ index, int64_t n,
+                             int64_t* __restrict__ out) {
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) out[i] = table[index[i]];
+}
+
+template <class K>
+static size_t sort_temp_bytes(int64_t n) {
+    size_t tb = 0;
+    K* k = nullptr;
+    int32_t* v = nullptr;
+    (void)rocprim::radix_sort_pairs(nullptr, tb, k, k, v, v, (size_t)(n > 0 ? n : 1), 0, (unsigned)(8 * sizeof(K)), (hipStream_t)0);
+    return align_up(tb, 256) + 256;
+}
+
+}  // namespace gsat
+
+using namespace gsat;
+
+extern "C" {
+
+int gsat_abi_version(void) { return GSAT_ABI_VERSION; }
+const char* gsat_last_error(void) { return gsat::get_error(); }
+
+size_t gsat_csr_workspace_bytes(int64_t E, int64_t /*num_rows*/) {
+    size_t e = (size_t)(E > 0 ? E : 1);
+    return 3 * align_up(e * 4, 256) + sort_temp_bytes<uint32_t>(E);
+}
+
+size_t gsat_rev_workspace_bytes(int64_t E) {
+    size_t e = (size_t)(E > 0 ? E : 1);
+    return 4 * align_up(e * 8, 256) + 3 * align_up(e * 4, 256) + sort_temp_bytes<uint64_t>(E);
+}
+
+int gsat_build_csr(const int64_t* rows, const int64_t* other, int64_t E, int64_t num_rows, int32_t* rowptr,
+                   int32_t* other_sorted, int32_t* perm, int32_t* err_flag, void* workspace, size_t ws_bytes,
+                   void* stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    GSAT_REQUIRE(E >= 0 && num_rows >= 0 && rowptr && err_flag, GSAT_ERR_ARG, "gsat_build_csr: bad argument");
+    GSAT_REQUIRE(E < (1ll << 31) && num_rows < (1ll << 31), GSAT_ERR_UNSUPPORTED, "gsat_build_csr: >2^31 entries");
+    if (E == 0) {
+        GSAT_CHECK_HIP(hipMemsetAsync(rowptr, 0, (size_t)(num_rows + 1) * sizeof(int32_t), stream));
+        return GSAT_OK;
+    }
+    GSAT_REQUIRE(rows && perm && num_rows > 0, GSAT_ERR_ARG, "gsat_build_csr: null rows/perm");
+    Arena ar(workspace, ws_bytes);
+    uint32_t* keys_in = ar.take<uint32_t>(E);
+    uint32_t* keys_out = ar.take<uint32_t>(E);
+    int32_t* ids = ar.take<int32_t>(E);
+    size_t tb = sort_temp_bytes<uint32_t>(E);
+    char* temp = ar.take<char>(tb);
+    GSAT_REQUIRE(ar.ok() && temp, GSAT_ERR_WORKSPACE, "gsat_build_csr: workspace %zu < %zu", ws_bytes, ar.off);
+
+    const int B = 256;
+    k_make_row_keys<<<ceil_div(E, B), B, 0, stream>>>(rows, E, num_rows, keys_in, ids, err_flag);
+    GSAT_LAUNCH_CHECK();
+    int end_bit = bits_for((uint64_t)(num_rows - 1));
+    GSAT_CHECK_HIP(rocprim::radix_sort_pairs(temp, tb, keys_in, keys_out, ids, perm, (size_t)E, 0, (unsigned)end_bit, stream));
+    k_lower_bounds<uint32_t><<<ceil_div(num_rows + 1, B), B, 0, stream>>>(keys_out, E, num_rows, rowptr);
+    GSAT_LAUNCH_CHECK();
+    if (other && other_sorted) {
+        k_gather_narrow<<<ceil_div(E, B), B, 0, stream>>>(other, perm, E, other_sorted);
+        GSAT_LAUNCH_CHECK();
+    }
+    return GSAT_OK;
+}
+
+int gsat_reverse_edge_perm(const int64_t* edge_index, int64_t E, int64_t N, int32_t* rev, int32_t* flags,
+                           void* workspace, size_t ws_bytes, void* stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    GSAT_REQUIRE(E >= 0 && N >= 0 && flags, GSAT_ERR_ARG, "gsat_reverse_edge_perm: bad argument");
+    GSAT_REQUIRE(E < (1ll << 31) && N < (1ll << 31), GSAT_ERR_UNSUPPORTED, "gsat_reverse_edge_perm: >2^31 entries");
+    GSAT_CHECK_HIP(hipMemsetAsync(flags, 0, 2 * sizeof(int32_t), stream));
+    if (E == 0) {
+        k_finish_flags<<<1, 1, 0, stream>>>(flags);
+        GSAT_LAUNCH_CHECK();
+        return GSAT_OK;
+    }
+    GSAT_REQUIRE(edge_index && rev && N > 0, GSAT_ERR_ARG, "gsat_reverse_edge_perm: null pointer");
+    Arena ar(workspace, ws_bytes);
+    uint64_t* k = ar.take<uint64_t>(E);
+    uint64_t* kt = ar.take<uint64_t>(E);
+    uint64_t* ks = ar.take<uint64_t>(E);
+    uint64_t* kts = ar.take<uint64_t>(E);
+    int32_t* ids = ar.take<int32_t>(E);
+    int32_t* p = ar.take<int32_t>(E);
+    int32_t* q = ar.take<int32_t>(E);
+    size_t tb = sort_temp_bytes<uint64_t>(E);
+    char* temp = ar.take<char>(tb);
+    GSAT_REQUIRE(ar.ok() && temp, GSAT_ERR_WORKSPACE, "gsat_reverse_edge_perm: workspace %zu < %zu", ws_bytes, ar.off);
+    const int B = 256;
+    k_make_edge_keys<<<ceil_div(E, B), B, 0, stream>>>(edge_index, E, N, k, kt, ids);
+    GSAT_LAUNCH_CHECK();
+    int end_bit = bits_for((uint64_t)N * (uint64_t)N - 1);
+    GSAT_CHECK_HIP(rocprim::radix_sort_pairs(temp, tb, k, ks, ids, p, (size_t)E, 0, (unsigned)end_bit, stream));
+    GSAT_CHECK_HIP(rocprim::radix_sort_pairs(temp, tb, kt, kts, ids, q, (size_t)E, 0, (unsigned)end_bit, stream));
+    k_pair_reverse<<<ceil_div(E, B), B, 0, stream>>>(ks, kts, p, q, E, rev, flags);
+    GSAT_LAUNCH_CHECK();
+    k_finish_flags<<<1, 1, 0, stream>>>(flags);
+    GSAT_LAUNCH_CHECK();
+    return GSAT_OK;
+}
+
+int gsat_segment_ptr(const int64_t* seg_ids, int64_t n, int64_t num_seg, int32_t* ptr, int32_t* flags, void* stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    GSAT_REQUIRE(n >= 0 && num_seg >= 0 && ptr && flags, GSAT_ERR_ARG, "gsat_segment_ptr: bad argument");
+    GSAT_REQUIRE(n < (1ll << 31), GSAT_ERR_UNSUPPORTED, "gsat_segment_ptr: >2^31 rows");
+    const int B = 256;
+    GSAT_CHECK_HIP(hipMemsetAsync(flags, 0, sizeof(int32_t), stream));
+    if (n > 0) {
+        GSAT_REQUIRE(seg_ids, GSAT_ERR_ARG, "gsat_segment_ptr: null ids");
+        k_check_sorted<<<ceil_div(n, B), B, 0, stream>>>(seg_ids, n, num_seg, flags);
+        GSAT_LAUNCH_CHECK();
+    }
+    k_lower_bounds<int64_t><<<ceil_div(num_seg + 1, B), B, 0, stream>>>(seg_ids, n, num_seg, ptr);
+    GSAT_LAUNCH_CHECK();
+    return GSAT_OK;
+}
+
+int gsat_gather_i64(const int64_t* table, const int64_t* index, int64_t n, int64_t* out, void* stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    GSAT_REQUIRE(n >= 0, GSAT_ERR_ARG, "gsat_gather_i64: bad n");
+    if (n == 0) return GSAT_OK;
+    GSAT_REQUIRE(table && index && out, GSAT_ERR_ARG, "gsat_gather_i64: null pointer");
+    k_gather_i64<<<ceil_div(n, 256), 256, 0, stream>>>(table, index, n, out);
+    GSAT_LAUNCH_CHECK();
+    return GSAT_OK;
+}
+
+}  // extern "C"

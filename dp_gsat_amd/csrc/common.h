@@ -1,0 +1,103 @@
+// Shared host/device helpers for libgsat_hip (gfx950 / CDNA4 only).
+#pragma once
+#include <cstring>
+#include <cstdint>
+#include <cstdio>
+#include <cstdarg>
+#include <hip/hip_runtime.h>
+
+#include "../../include/gsat_hip.h"
+
+namespace gsat {
+
+// ---- error plumbing: no exceptions cross the C ABI ------------------------------------------
+void set_error(const char* fmt, ...);
+const char* get_error();
+
+#define GSAT_CHECK_HIP(expr)                                                                  \
+    do {                                                                                      \
+        hipError_t _e = (expr);                                                               \
+        if (_e != hipSuccess) {                                                               \
+            gsat::set_error("%s:%d: %s -> %s", __FILE__, __LINE__, #expr, hipGetErrorString(_e)); \
+            return GSAT_ERR_HIP;                                                              \
+        }                                                                                     \
+    } while (0)
+
+#define GSAT_REQUIRE(cond, code, ...)                                                         \
+    do {                                                                                      \
+        if (!(cond)) {                                                                        \
+            gsat::set_error(__VA_ARGS__);                                                     \
+            return (code);                                                                    \
+        }                                                                                     \
+    } while (0)
+
+#define GSAT_LAUNCH_CHECK() GSAT_CHECK_HIP(hipGetLastError())
+
+static inline int64_t ceil_div(int64_t a, int64_t b) { return (a + b - 1) / b; }
+static inline size_t align_up(size_t a, size_t b) { return (a + b - 1) / b * b; }
+
+// Bump allocator over a caller-provided workspace (the library never allocates device memory).
+struct Arena {
+    char* base;
+    size_t cap, off;
+    Arena(void* p, size_t bytes) : base(static_cast<char*>(p)), cap(bytes), off(0) {}
+    template <class T> T* take(size_t n) {
+        size_t b = align_up(n * sizeof(T), 256);
+        if (base == nullptr || off + b > cap) { off += b; return nullptr; }
+        T* r = reinterpret_cast<T*>(base + off);
+        off += b;
+        return r;
+    }
+    bool ok() const { return base != nullptr && off <= cap; }
+};
+
+// ---- device helpers -------------------------------------------------------------------------
+#ifdef __HIPCC__
+constexpr int WAVE = 64;
+
+// sum over the `width` consecutive lanes of an aligned lane group (width = power of two <= 64)
+template <int WIDTH> __device__ __forceinline__ float group_sum(float v) {
+#pragma unroll
+    for (int o = WIDTH / 2; o > 0; o >>= 1) v += __shfl_xor(v, o, WIDTH);
+    return v;
+}
+
+__device__ __forceinline__ float4 ld4(const float* p) { return *reinterpret_cast<const float4*>(p); }
+__device__ __forceinline__ void st4(float* p, float4 v) { *reinterpret_cast<float4*>(p) = v; }
+__device__ __forceinline__ float4 f4zero() { return make_float4(0.f, 0.f, 0.f, 0.f); }
+__device__ __forceinline__ float4 f4fma(float a, float4 x, float4 acc) {
+    acc.x = fmaf(a, x.x, acc.x); acc.y = fmaf(a, x.y, acc.y);
+    acc.z = fmaf(a, x.z, acc.z); acc.w = fmaf(a, x.w, acc.w);
+    return acc;
+}
+__device__ __forceinline__ float f4dot(float4 a, float4 b) {
+    return fmaf(a.x, b.x, fmaf(a.y, b.y, fmaf(a.z, b.z, a.w * b.w)));
+}
+
+// Philox4x32-10 counter RNG: one 128-bit draw per (row, 4-column group); keep-mask decisions are
+// reproducible between forward and backward from (seed, stream id, row, column) alone.
+__device__ __forceinline__ uint4 philox4x32(uint64_t seed, uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3) {
+    uint32_t k0 = (uint32_t)seed, k1 = (uint32_t)(seed >> 32);
+#pragma unroll
+    for (int r = 0; r < 10; ++r) {
+        uint64_t p0 = (uint64_t)0xD2511F53u * c0;
+        uint64_t p1 = (uint64_t)0xCD9E8D57u * c2;
+        uint32_t n0 = (uint32_t)(p1 >> 32) ^ c1 ^ k0;
+        uint32_t n1 = (uint32_t)p1;
+        uint32_t n2 = (uint32_t)(p0 >> 32) ^ c3 ^ k1;
+        uint32_t n3 = (uint32_t)p0;
+        c0 = n0; c1 = n1; c2 = n2; c3 = n3;
+        k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+    }
+    return make_uint4(c0, c1, c2, c3);
+}
+// keep-probability test for column `col` of row `row` in RNG stream `sid`
+__device__ __forceinline__ float philox_keep(uint64_t seed, uint32_t sid, uint32_t row, uint32_t col, float p_drop) {
+    uint4 r = philox4x32(seed, row, col >> 2, sid, 0x5A17u);
+    uint32_t w = (col & 3) == 0 ? r.x : (col & 3) == 1 ? r.y : (col & 3) == 2 ? r.z : r.w;
+    float u = (float)(w >> 8) * (1.0f / 16777216.0f);   // [0,1)
+    return u >= p_drop ? 1.0f : 0.0f;
+}
+#endif
+
+}  // namespace gsat

@@ -1,0 +1,180 @@
+"""Per-batch integer bookkeeping, built once on the device and cached.
+
+The reference re-derives all of this on every forward (a coalesce/sort in ``is_undirected``, a sort in
+``sort_edge_index``, two ``argsort`` in ``reorder_like`` -- example/gsat.py:80-83,
+src/utils/utils.py:19-25 -- and a scatter index per ``propagate`` call, src/models/conv_layers.py:21).
+Here a collated batch gets one :class:`BatchIndex` holding int32 CSR views of ``edge_index`` by
+destination and by source, the reverse-edge permutation and the per-graph segment pointers.
+"""
+from __future__ import annotations
+
+from collections import OrderedDict
+from typing import Optional
+
+import torch
+
+from . import _lib
+from ._lib import call, ptr, stream
+
+
+def _i32(n, device):
+    return torch.empty(max(int(n), 1), dtype=torch.int32, device=device)[: int(n)]
+
+
+class BatchIndex:
+    def __init__(self, edge_index: torch.Tensor, num_nodes: int):
+        if edge_index.dim() != 2 or edge_index.shape[0] != 2 or edge_index.dtype != torch.int64:
+            raise ValueError("edge_index must be an int64 tensor of shape [2, E]")
+        _lib.load()
+        if not edge_index.is_cuda:
+            raise _lib.GsatHipError("BatchIndex needs a ROCm edge_index (no CPU fallback)")
+        self._key_tensor = edge_index          # keeps the keyed storage alive while cached
+        self.edge_index = edge_index.contiguous()
+        self.N = int(num_nodes)
+        self.E = int(edge_index.shape[1])
+        self.device = edge_index.device
+        dev = self.device
+        E, N = self.E, self.N
+        ws_bytes = max(call_size("gsat_csr_workspace_bytes", E, N), 256)
+        ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
+        self._err = torch.zeros(4, dtype=torch.int32, device=dev)
+        src, dst = self.edge_index[0], self.edge_index[1]
+        # CSR by destination: the forward aggregation order
+        self.rowptr_dst = torch.empty(N + 1, dtype=torch.int32, device=dev)
+        self.src_by_dst = _i32(E, dev)
+        self.eid_by_dst = _i32(E, dev)
+        call("gsat_build_csr", ptr(dst), ptr(src), E, N, ptr(self.rowptr_dst), ptr(self.src_by_dst),
+             ptr(self.eid_by_dst), ptr(self._err), ptr(ws), ws_bytes, stream())
+        # CSR by source: the transposed structure used by every backward
+        self.rowptr_src = torch.empty(N + 1, dtype=torch.int32, device=dev)
+        self.dst_by_src = _i32(E, dev)
+        self.eid_by_src = _i32(E, dev)
+        call("gsat_build_csr", ptr(src), ptr(dst), E, N, ptr(self.rowptr_src), ptr(self.dst_by_src),
+             ptr(self.eid_by_src), ptr(self._err), ptr(ws), ws_bytes, stream())
+        self._checked = False
+        self._rev = None
+        self._undirected = None
+        self._slot_dst_of_srcslot = None
+        self._graphs = {}
+
+    # -- validation (one host sync, deferred until something needs a host-side decision) --------
+    def check(self):
+        if not self._checked:
+            if int(self._err[0].item()) != 0:
+                raise ValueError("edge_index contains node ids outside [0, num_nodes)")
+            self._checked = True
+
+    # -- reverse-edge permutation / undirected flag ----------------------------------------------
+    def _build_rev(self):
+        E, N, dev = self.E, self.N, self.device
+        ws_bytes = max(call_size("gsat_rev_workspace_bytes", E), 256)
+        ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
+        rev = _i32(E, dev)
+        flags = torch.zeros(2, dtype=torch.int32, device=dev)
+        call("gsat_reverse_edge_perm", ptr(self.edge_index), E, N, ptr(rev), ptr(flags), ptr(ws), ws_bytes, stream())
+        f = flags.tolist()                       # the reference syncs here too (python `if is_undirected`)
+        self._undirected = bool(f[0])
+        self._rev = rev if self._undirected else None
+
+    @property
+    def is_undirected(self) -> bool:
+        if self._undirected is None:
+            self._build_rev()
+        return self._undirected
+
+    @property
+    def rev(self) -> Optional[torch.Tensor]:
+        """int32[E] reverse-edge permutation, or None when the edge set is not symmetric."""
+        if self._undirected is None:
+            self._build_rev()
+        return self._rev
+
+    @property
+    def slot_dst_of_srcslot(self) -> torch.Tensor:
+        """For slot k of the by-source CSR, the slot of the same edge in the by-destination CSR."""
+        if self._slot_dst_of_srcslot is None:
+            inv = torch.empty(self.E, dtype=torch.int32, device=self.device)
+            inv[self.eid_by_dst.long()] = torch.arange(self.E, dtype=torch.int32, device=self.device)
+            self._slot_dst_of_srcslot = inv[self.eid_by_src.long()].contiguous()
+        return self._slot_dst_of_srcslot
+
+    # -- per-graph segments ----------------------------------------------------------------------
+    def graphs(self, batch: torch.Tensor, num_graphs: Optional[int] = None) -> "GraphSegments":
+        key = (batch.data_ptr(), batch._version, int(batch.shape[0]))
+        seg = self._graphs.get(key)
+        if seg is None:
+            seg = GraphSegments(self, batch, num_graphs)
+            self._graphs = {key: seg}
+        return seg
+
+
+class GraphSegments:
+    """Segment pointers of the ``batch`` vector and of the edges grouped by graph."""
+
+    def __init__(self, index: BatchIndex, batch: torch.Tensor, num_graphs: Optional[int] = None):
+        if batch.dtype != torch.int64 or batch.dim() != 1:
+            raise ValueError("batch must be an int64 vector")
+        self.index = index
+        self.batch = batch.contiguous()
+        dev = batch.device
+        n = int(batch.shape[0])
+        if num_graphs is None:
+            num_graphs = int(batch.max().item()) + 1 if n > 0 else 0     # reference: batch.max()+1 (sync)
+        self.G = int(num_graphs)
+        self.node_ptr = torch.empty(self.G + 1, dtype=torch.int32, device=dev)
+        flags = torch.zeros(1, dtype=torch.int32, device=dev)
+        call("gsat_segment_ptr", ptr(self.batch), n, self.G, ptr(self.node_ptr), ptr(flags), stream())
+        self._flags = flags
+        self._edge = None
+
+    def check(self):
+        if int(self._flags.item()) != 0:
+            raise ValueError("`batch` must be non-decreasing with ids in [0, num_graphs)")
+
+    @property
+    def edge_segments(self):
+        """(edge_ptr int32[G+1], edge_order int32[E], edge_graph int64[E]): edges grouped by the graph
+        of their SOURCE node -- ``batch[col]`` with ``col = edge_index[0]`` (example/gsat.py:133-136)."""
+        if self._edge is None:
+            ix = self.index
+            E, dev = ix.E, ix.device
+            eg = torch.empty(max(E, 1), dtype=torch.int64, device=dev)[:E]
+            call("gsat_gather_i64", ptr(self.batch), ptr(ix.edge_index[0].contiguous()), E, ptr(eg), stream())
+            ws_bytes = max(call_size("gsat_csr_workspace_bytes", E, self.G), 256)
+            ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
+            eptr = torch.empty(self.G + 1, dtype=torch.int32, device=dev)
+            order = _i32(E, dev)
+            err = torch.zeros(1, dtype=torch.int32, device=dev)
+            call("gsat_build_csr", ptr(eg), None, E, self.G, ptr(eptr), None, ptr(order), ptr(err), ptr(ws), ws_bytes, stream())
+            self._edge = (eptr, order, eg)
+        return self._edge
+
+
+def call_size(name, *args) -> int:
+    return int(getattr(_lib.load(), name)(*args))
+
+
+# ---------------------------------------------------------------------------------------------
+# cache: the reference passes the same `data.edge_index` tensor to get_emb, the extractor and the
+# masked forward of one step (example/gsat.py:75-89); keying on (storage pointer, version, shape)
+# stays correct if the caller mutates edge_index in place (version bump) or swaps the tensor.
+# ---------------------------------------------------------------------------------------------
+_CACHE: "OrderedDict[tuple, BatchIndex]" = OrderedDict()
+_CACHE_SIZE = 8
+
+
+def get_index(edge_index: torch.Tensor, num_nodes: int) -> BatchIndex:
+    key = (edge_index.data_ptr(), edge_index._version, tuple(edge_index.shape), int(num_nodes), str(edge_index.device))
+    ix = _CACHE.get(key)
+    if ix is None:
+        ix = BatchIndex(edge_index, num_nodes)
+        _CACHE[key] = ix
+        while len(_CACHE) > _CACHE_SIZE:
+            _CACHE.popitem(last=False)
+    else:
+        _CACHE.move_to_end(key)
+    return ix
+
+
+def clear_cache():
+    _CACHE.clear()

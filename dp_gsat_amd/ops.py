@@ -1,0 +1,102 @@
+"""torch.autograd.Function wrappers around the C ABI (include/gsat_hip.h).
+
+Every forward/backward here is one or two kernel launches on torch's current stream; PyTorch only
+provides the device memory.  None of these has a CPU path.
+"""
+from __future__ import annotations
+
+from typing import Optional
+
+import torch
+
+from ._lib import call, ptr, stream
+from .graph_index import BatchIndex
+
+
+def _f32c(t: Optional[torch.Tensor]) -> Optional[torch.Tensor]:
+    if t is None:
+        return None
+    if t.dtype != torch.float32:
+        raise TypeError("dp_gsat_amd kernels compute in fp32; got " + str(t.dtype))
+    return t.contiguous()
+
+
+def _flat_att(att: Optional[torch.Tensor], E: int) -> Optional[torch.Tensor]:
+    """edge_atten is [E,1] in the reference (src/models/conv_layers.py:31-32); kernels take [E]."""
+    if att is None:
+        return None
+    if att.numel() != E:
+        raise ValueError(f"edge_atten has {att.numel()} entries, expected {E}")
+    return _f32c(att).view(-1)
+
+
+class MaskedSumAggregate(torch.autograd.Function):
+    """out = (1+eps)*x + sum_{e: dst=i} att_e * msg_e   (GINConv / GINEConv message passing).
+
+    replaces: GINConv.forward/message, GINEConv.forward/message (src/models/conv_layers.py:14-66)."""
+
+    @staticmethod
+    def forward(ctx, x, att, edge_emb, index: BatchIndex, self_coef: float):
+        x = _f32c(x)
+        attf = _flat_att(att, index.E)
+        edge_emb = _f32c(edge_emb)
+        N, H = x.shape
+        if N != index.N:
+            raise ValueError(f"x has {N} rows but the index was built for {index.N} nodes")
+        if edge_emb is not None and tuple(edge_emb.shape) != (index.E, H):
+            raise ValueError("Node and edge feature dimensionalities do not match. Consider setting the "
+                             "'edge_dim' attribute of 'GINEConv'")     # src/models/conv_layers.py:54-57
+        out = torch.empty_like(x)
+        call("gsat_aggr_sum_fwd", ptr(x), None, ptr(attf), ptr(edge_emb), ptr(index.rowptr_dst),
+             ptr(index.src_by_dst), ptr(index.eid_by_dst), N, H, float(self_coef), ptr(out), stream())
+        ctx.save_for_backward(x, attf, edge_emb)
+        ctx.index, ctx.self_coef = index, float(self_coef)
+        ctx.att_shape = None if att is None else att.shape
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        x, attf, edge_emb = ctx.saved_tensors
+        index = ctx.index
+        dout = _f32c(dout)
+        N, H = x.shape
+        need_att = attf is not None and ctx.needs_input_grad[1]
+        need_ee = edge_emb is not None and ctx.needs_input_grad[2]
+        dx = torch.empty_like(x)
+        datt = torch.empty(index.E, dtype=torch.float32, device=x.device) if need_att else None
+        dee = torch.empty_like(edge_emb) if need_ee else None
+        call("gsat_aggr_sum_bwd", ptr(x), ptr(attf), ptr(edge_emb), ptr(dout), ptr(index.rowptr_src),
+             ptr(index.dst_by_src), ptr(index.eid_by_src), N, H, ctx.self_coef, ptr(dx), ptr(datt), ptr(dee), stream())
+        return dx, (datt.view(ctx.att_shape) if need_att else None), dee, None, None
+
+
+def masked_sum_aggregate(x, index, att=None, edge_emb=None, eps: float = 0.0):
+    return MaskedSumAggregate.apply(x, att, edge_emb, index, 1.0 + eps)
+
+
+class SegmentPool(torch.autograd.Function):
+    """global_add_pool / global_mean_pool over a sorted ``batch`` (src/models/gin.py:34, pna.py:47)."""
+
+    @staticmethod
+    def forward(ctx, x, node_ptr, num_graphs: int, mean: bool):
+        x = _f32c(x)
+        H = x.shape[1]
+        out = torch.empty(num_graphs, H, dtype=torch.float32, device=x.device)
+        call("gsat_segment_pool_fwd", ptr(x), ptr(node_ptr), num_graphs, H, int(mean), ptr(out), stream())
+        ctx.save_for_backward(node_ptr)
+        ctx.n, ctx.mean = x.shape[0], bool(mean)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        (node_ptr,) = ctx.saved_tensors
+        dout = _f32c(dout)
+        G, H = dout.shape
+        dx = torch.empty(ctx.n, H, dtype=torch.float32, device=dout.device)
+        if node_ptr.numel() and ctx.n:
+            call("gsat_segment_pool_bwd", ptr(dout), ptr(node_ptr), G, H, int(ctx.mean), ptr(dx), stream())
+        return dx, None, None, None
+
+
+def segment_pool(x, segments, mean: bool):
+    return SegmentPool.apply(x, segments.node_ptr, segments.G, mean)

@@ -1,0 +1,129 @@
+/*
+ * gsat_hip.h -- C ABI of libgsat_hip.so, the MI355X (gfx950) implementation of GSAT's
+ * edge-attention -> stochastic mask -> masked message passing hot path.
+ *
+ * The reference (mihikamd/DP-GSAT) has no FFI: its boundary is a Python nn.Module protocol whose
+ * arithmetic runs inside torch-geometric / torch-scatter / torch-sparse kernels.  Each entry point
+ * below replaces the chain of third-party launches behind one reference call site, cited as
+ * "replaces: <file:line>" (paths relative to the reference root).
+ *
+ * Conventions
+ *   - every function returns 0 on success or a negative GSAT_ERR_* code; no exception crosses the
+ *     ABI; gsat_last_error() returns a thread-local message for the last failure on this thread.
+ *   - all tensor pointers are DEVICE pointers, contiguous row-major, fp32 unless typed otherwise;
+ *     edge_index / batch keep the reference's int64 API type, everything the library produces for
+ *     its own kernels (CSR arrays, permutations, segment pointers) is int32.
+ *   - the caller owns every buffer (inputs, outputs, workspaces); the library never allocates,
+ *     frees or retains device memory, never synchronises the host, and only enqueues work on the
+ *     `stream` argument (a hipStream_t passed as void*), so calls are graph-capturable and
+ *     re-entrant (forward on the Python thread, backward on autograd's worker thread).
+ *   - "nullable" pointers may be NULL to switch the corresponding term off.
+ */
+#ifndef GSAT_HIP_H
+#define GSAT_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define GSAT_ABI_VERSION 1
+
+#define GSAT_OK 0
+#define GSAT_ERR_HIP (-1)        /* a HIP runtime call failed */
+#define GSAT_ERR_ARG (-2)        /* bad argument (null pointer, negative extent, unsupported width) */
+#define GSAT_ERR_WORKSPACE (-3)  /* workspace too small */
+#define GSAT_ERR_UNSUPPORTED (-4)
+#define GSAT_ERR_BLAS (-5)
+
+int gsat_abi_version(void);
+const char* gsat_last_error(void);
+
+/* =============================== integer edge bookkeeping ==================================== */
+
+/* Workspace (bytes) needed by gsat_build_csr / gsat_reverse_edge_perm for E edges. */
+size_t gsat_csr_workspace_bytes(int64_t num_edges, int64_t num_rows);
+size_t gsat_rev_workspace_bytes(int64_t num_edges);
+
+/*
+ * Group the E edge slots by `rows` (stable): perm = edge ids sorted by (rows[e], e),
+ * rowptr[r]..rowptr[r+1] = slots of row r, other_sorted[k] = (int32) other[perm[k]].
+ * replaces: the scatter index handling inside MessagePassing.propagate
+ *           (src/models/conv_layers.py:21,44,163) -- done once per batch instead of per launch.
+ * rows/other: int64[E]; rowptr: int32[num_rows+1]; other_sorted, perm: int32[E].
+ * err_flag (int32[1], device, caller-zeroed): incremented for every out-of-range row id.
+ */
+int gsat_build_csr(const int64_t* rows, const int64_t* other, int64_t num_edges, int64_t num_rows,
+                   int32_t* rowptr, int32_t* other_sorted, int32_t* perm, int32_t* err_flag,
+                   void* workspace, size_t workspace_bytes, void* stream);
+
+/*
+ * rev[k] = id of the edge (dst_k, src_k); flags[0] = 1 iff the edge multiset equals its transpose
+ * (is_undirected), flags[1] = number of sorted positions where edge and transposed keys differ.
+ * Pairing rule for duplicate edges: stable (key, edge id) order on both sides.
+ * replaces: is_undirected + torch_sparse.transpose + reorder_like
+ *           (example/gsat.py:80-83, src/run_gsat.py:231-247, src/utils/utils.py:19-25).
+ * edge_index: int64[2,E]; rev: int32[E]; flags: int32[2].
+ */
+int gsat_reverse_edge_perm(const int64_t* edge_index, int64_t num_edges, int64_t num_nodes,
+                           int32_t* rev, int32_t* flags, void* workspace, size_t workspace_bytes,
+                           void* stream);
+
+/*
+ * Segment pointer of a non-decreasing id vector (PyG `batch`): ptr[g]..ptr[g+1] = rows of
+ * segment g.  flags[0] counts order violations / out-of-range ids (0 = valid input).
+ * replaces: the per-call `degree(batch)` + scatter index of InstanceNorm and global pools
+ *           (src/utils/get_model.py:50-51, src/models/gin.py:34, src/models/pna.py:47).
+ */
+int gsat_segment_ptr(const int64_t* seg_ids, int64_t num_rows, int64_t num_segments, int32_t* ptr,
+                     int32_t* flags, void* stream);
+
+/* out[e] = batch[index[e]]  (edge -> graph id, `batch[col]` of example/gsat.py:136). int64 out. */
+int gsat_gather_i64(const int64_t* table, const int64_t* index, int64_t n, int64_t* out, void* stream);
+
+/* ============================ masked message passing: sum (GIN / GINE) ====================== */
+
+/*
+ * out[i,:] = self_coef * self_rows[i,:] + sum_{k in row i} w_k * msg_k
+ *   msg_k = x[col[k],:]                                   (edge_emb == NULL : GINConv)
+ *         = relu(x[col[k],:] + edge_emb[eid[k],:])         (edge_emb != NULL : GINEConv)
+ *   w_k   = att[eid[k]]  (att == NULL -> 1)
+ * replaces: GINConv.forward/message and GINEConv.forward/message up to `self.nn`
+ *           (src/models/conv_layers.py:14-34, 37-66): index_select + mul + scatter_sum + add.
+ * x, self_rows: [N,H]; att: [E] nullable; edge_emb: [E,H] nullable; rowptr int32[N+1];
+ * col, eid: int32[E]; out: [N,H].  self_rows may be NULL (-> x).  H % 4 == 0, H <= 2048.
+ */
+int gsat_aggr_sum_fwd(const float* x, const float* self_rows, const float* att, const float* edge_emb,
+                      const int32_t* rowptr, const int32_t* col, const int32_t* eid,
+                      int64_t num_rows, int64_t H, float self_coef, float* out, void* stream);
+
+/*
+ * Backward of gsat_aggr_sum_fwd over the TRANSPOSED structure (edges grouped by source node j):
+ *   dx[j,:]   = self_coef * dout[j,:] + sum_{k in srcrow j} att_k * dout[dst[k],:] (* [pre_k > 0])
+ *   datt[eid[k]]        = < msg_k , dout[dst[k],:] >
+ *   dedge_emb[eid[k],:] = att_k * dout[dst[k],:] * [pre_k > 0]        (GINE only)
+ * replaces: autograd backward of the above (example/trainer.py:34, src/run_gsat.py:634).
+ * rowptr_src int32[N+1]; dst_sorted, eid_src int32[E]; datt nullable; dedge_emb nullable.
+ */
+int gsat_aggr_sum_bwd(const float* x, const float* att, const float* edge_emb, const float* dout,
+                      const int32_t* rowptr_src, const int32_t* dst_sorted, const int32_t* eid_src,
+                      int64_t num_rows, int64_t H, float self_coef, float* dx, float* datt,
+                      float* dedge_emb, void* stream);
+
+/* ================================ global pools / segment ops ================================ */
+
+/*
+ * out[g,:] = sum (mean != 0: mean, count clamped >= 1) of x[ptr[g]..ptr[g+1],:].
+ * replaces: global_add_pool / global_mean_pool (src/models/gin.py:34,53; src/models/pna.py:47,62).
+ */
+int gsat_segment_pool_fwd(const float* x, const int32_t* ptr, int64_t num_segments, int64_t H,
+                          int mean, float* out, void* stream);
+int gsat_segment_pool_bwd(const float* dout, const int32_t* ptr, int64_t num_segments, int64_t H,
+                          int mean, float* dx, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* GSAT_HIP_H */

@@ -1,0 +1,291 @@
+"""nn.Module restatement of the reference's backbones / extractor / GSAT step (ORACLE, test-only).
+
+Module structure reproduces the reference's attribute names so that ``state_dict`` keys are the
+reference's: GIN ``node_encoder, edge_encoder, convs.{i}.eps, convs.{i}.nn.{0,1,3},
+convs.{i}.lin, fc_out.0``; PNA ``convs.{i}.post_nn.0, batch_norms.{i}.module, fc_out.{0,2,4}``;
+extractor ``feature_extractor.{0,4,8}``.  Randomness (concrete noise ``u``, extractor dropout
+masks) is always passed in explicitly; backbone dropout uses torch's generator (set p=0 for parity).
+"""
+from __future__ import annotations
+
+from typing import Optional
+
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from . import bookkeeping as bk
+from . import ops
+
+# [3P] ogb 1.3.2 ogb/utils/features.py get_atom_feature_dims / get_bond_feature_dims
+ATOM_FEATURE_DIMS = [119, 5, 12, 12, 10, 6, 6, 2, 2]
+BOND_FEATURE_DIMS = [5, 6, 2]
+
+
+class _CatEncoder(nn.Module):
+    """[3P] ogb AtomEncoder / BondEncoder: sum of per-column nn.Embedding lookups, xavier_uniform init."""
+
+    def __init__(self, emb_dim, dims, list_name):
+        super().__init__()
+        lst = nn.ModuleList()
+        for d in dims:
+            e = nn.Embedding(d, emb_dim)
+            nn.init.xavier_uniform_(e.weight.data)
+            lst.append(e)
+        setattr(self, list_name, lst)
+        self._list_name = list_name
+
+    def forward(self, x):
+        lst = getattr(self, self._list_name)
+        out = 0
+        for i in range(x.shape[1]):
+            out = out + lst[i](x[:, i])
+        return out
+
+
+class AtomEncoder(_CatEncoder):
+    def __init__(self, emb_dim):
+        super().__init__(emb_dim, ATOM_FEATURE_DIMS, "atom_embedding_list")
+
+
+class BondEncoder(_CatEncoder):
+    def __init__(self, emb_dim):
+        super().__init__(emb_dim, BOND_FEATURE_DIMS, "bond_embedding_list")
+
+
+class InstanceNorm(nn.Module):
+    """parameter-free placeholder so Sequential indices match (src/utils/get_model.py:64)."""
+
+    def __init__(self, channels):
+        super().__init__()
+        self.channels = channels
+
+
+class MLP(nn.Sequential):
+    """src/utils/get_model.py:57-68 (+ BatchSequential :47-54)."""
+
+    def __init__(self, channels, dropout, bias=True):
+        m = []
+        for i in range(1, len(channels)):
+            m.append(nn.Linear(channels[i - 1], channels[i], bias))
+            if i < len(channels) - 1:
+                m.append(InstanceNorm(channels[i]))
+                m.append(nn.ReLU())
+                m.append(nn.Dropout(dropout))
+        super().__init__(*m)
+        self.p = dropout
+
+    def weights(self):
+        return [(mod.weight, mod.bias) for mod in self if isinstance(mod, nn.Linear)]
+
+    def forward(self, inputs, batch, num_seg=None, masks=None):
+        num_seg = int(batch.max()) + 1 if num_seg is None else num_seg
+        return ops.mlp_forward(inputs, batch, num_seg, self.weights(), self.p, masks, self.training)
+
+
+class ExtractorMLP(nn.Module):
+    """example/gsat.py:120-139."""
+
+    def __init__(self, hidden_size, learn_edge_att, dropout=0.5):
+        super().__init__()
+        self.learn_edge_att = learn_edge_att
+        if learn_edge_att:
+            self.feature_extractor = MLP([hidden_size * 2, hidden_size * 4, hidden_size, 1], dropout=dropout)
+        else:
+            self.feature_extractor = MLP([hidden_size * 1, hidden_size * 2, hidden_size, 1], dropout=dropout)
+
+    def forward(self, emb, edge_index, batch, masks=None):
+        G = int(batch.max()) + 1
+        return ops.extractor_forward(emb, edge_index, batch, G, self.feature_extractor.weights(),
+                                     self.learn_edge_att, self.feature_extractor.p, masks, self.training)
+
+
+def _gin_mlp(i, o):
+    return nn.Sequential(nn.Linear(i, o), nn.BatchNorm1d(o), nn.ReLU(inplace=True), nn.Linear(o, o))
+
+
+class GINConv(nn.Module):
+    """src/models/conv_layers.py:14-34 ; [3P] BaseGINConv(nn, eps=0, train_eps=False): eps is a buffer."""
+
+    def __init__(self, nn_):
+        super().__init__()
+        self.nn = nn_
+        self.register_buffer("eps", torch.Tensor([0.0]))
+
+    def forward(self, x, edge_index, edge_attr=None, edge_atten=None):
+        return self.nn(ops.gin_aggregate(x, edge_index, edge_atten, float(self.eps)))
+
+
+class GINEConv(nn.Module):
+    """src/models/conv_layers.py:37-66 ; [3P] BaseGINEConv(nn, edge_dim=H) owns lin = Linear(edge_dim, H)."""
+
+    def __init__(self, nn_, edge_dim, in_channels):
+        super().__init__()
+        self.nn = nn_
+        self.register_buffer("eps", torch.Tensor([0.0]))
+        self.lin = nn.Linear(edge_dim, in_channels)
+
+    def forward(self, x, edge_index, edge_attr=None, edge_atten=None):
+        return self.nn(ops.gine_aggregate(x, edge_index, self.lin(edge_attr), edge_atten, float(self.eps)))
+
+
+class GIN(nn.Module):
+    """src/models/gin.py:12-81."""
+
+    def __init__(self, x_dim, edge_attr_dim, num_class, multi_label, model_config):
+        super().__init__()
+        self.n_layers = model_config["n_layers"]
+        H = model_config["hidden_size"]
+        self.edge_attr_dim = edge_attr_dim
+        self.dropout_p = model_config["dropout_p"]
+        self.use_edge_attr = model_config.get("use_edge_attr", True)
+        has_e = edge_attr_dim != 0 and self.use_edge_attr
+        if model_config.get("atom_encoder", False):
+            self.node_encoder = AtomEncoder(H)
+            if has_e:
+                self.edge_encoder = BondEncoder(H)
+        else:
+            self.node_encoder = nn.Linear(x_dim, H)
+            if has_e:
+                self.edge_encoder = nn.Linear(edge_attr_dim, H)
+        self.convs = nn.ModuleList()
+        for _ in range(self.n_layers):
+            self.convs.append(GINEConv(_gin_mlp(H, H), H, H) if has_e else GINConv(_gin_mlp(H, H)))
+        self.fc_out = nn.Sequential(nn.Linear(H, 1 if num_class == 2 and not multi_label else num_class))
+
+    def get_emb(self, x, edge_index, batch, edge_attr=None, edge_atten=None):
+        x = self.node_encoder(x)
+        if edge_attr is not None and self.use_edge_attr:
+            edge_attr = self.edge_encoder(edge_attr)
+        for i in range(self.n_layers):
+            x = self.convs[i](x, edge_index, edge_attr=edge_attr, edge_atten=edge_atten)
+            x = F.relu(x)
+            x = F.dropout(x, p=self.dropout_p, training=self.training)
+        return x
+
+    def get_pred_from_emb(self, emb, batch):
+        return self.fc_out(ops.global_add_pool(emb, batch, int(batch.max()) + 1))
+
+    def forward(self, x, edge_index, batch, edge_attr=None, edge_atten=None):
+        return self.get_pred_from_emb(self.get_emb(x, edge_index, batch, edge_attr, edge_atten), batch)
+
+
+class PNAConvSimple(nn.Module):
+    """src/models/conv_layers.py:96-191."""
+
+    def __init__(self, in_channels, out_channels, aggregators, scalers, deg, post_layers=1):
+        super().__init__()
+        self.aggregators, self.scalers = list(aggregators), list(scalers)
+        self.avg_deg = ops.pna_avg_deg(deg)
+        mods = [nn.Linear(len(aggregators) * len(scalers) * in_channels, out_channels)]
+        for _ in range(post_layers - 1):
+            mods += [nn.ReLU(), nn.Linear(out_channels, out_channels)]
+        self.post_nn = nn.Sequential(*mods)
+
+    def forward(self, x, edge_index, edge_attr=None, edge_atten=None):
+        return self.post_nn(ops.pna_aggregate(x, edge_index, edge_atten, self.aggregators, self.scalers,
+                                              self.avg_deg, edge_attr))
+
+
+class _PyGBatchNorm(nn.Module):
+    """[3P] torch_geometric.nn.BatchNorm: wrapper keeping nn.BatchNorm1d as ``.module``."""
+
+    def __init__(self, c):
+        super().__init__()
+        self.module = nn.BatchNorm1d(c)
+
+    def forward(self, x):
+        return self.module(x)
+
+
+class PNA(nn.Module):
+    """src/models/pna.py:12-78."""
+
+    def __init__(self, x_dim, edge_attr_dim, num_class, multi_label, model_config):
+        super().__init__()
+        H = model_config["hidden_size"]
+        self.n_layers = model_config["n_layers"]
+        self.dropout_p = model_config["dropout_p"]
+        self.edge_attr_dim = edge_attr_dim
+        use_e = model_config.get("use_edge_attr", True)
+        if model_config.get("atom_encoder", False):
+            self.node_encoder = AtomEncoder(H)
+            if edge_attr_dim != 0 and use_e:
+                self.edge_encoder = BondEncoder(H)
+        else:
+            self.node_encoder = nn.Linear(x_dim, H)
+            if edge_attr_dim != 0 and use_e:
+                self.edge_encoder = nn.Linear(edge_attr_dim, H)
+        aggregators = model_config["aggregators"]
+        scalers = ["identity", "amplification", "attenuation"] if model_config["scalers"] else ["identity"]
+        deg = model_config["deg"]
+        in_channels = (H * 2 if edge_attr_dim == 0 else H * 3) if use_e else H * 2
+        self.convs, self.batch_norms = nn.ModuleList(), nn.ModuleList()
+        for _ in range(self.n_layers):
+            self.convs.append(PNAConvSimple(in_channels, H, aggregators, scalers, deg, post_layers=1))
+            self.batch_norms.append(_PyGBatchNorm(H))
+        self.fc_out = nn.Sequential(nn.Linear(H, H // 2), nn.ReLU(), nn.Linear(H // 2, H // 4), nn.ReLU(),
+                                    nn.Linear(H // 4, 1 if num_class == 2 and not multi_label else num_class))
+
+    def get_emb(self, x, edge_index, batch, edge_attr, edge_atten=None):
+        x = self.node_encoder(x)
+        if edge_attr is not None:
+            edge_attr = self.edge_encoder(edge_attr)
+        for conv, bn in zip(self.convs, self.batch_norms):
+            h = F.relu(bn(conv(x, edge_index, edge_attr, edge_atten=edge_atten)))
+            x = h + x
+            x = F.dropout(x, self.dropout_p, training=self.training)
+        return x
+
+    def get_pred_from_emb(self, emb, batch):
+        return self.fc_out(ops.global_mean_pool(emb, batch, int(batch.max()) + 1))
+
+    def forward(self, x, edge_index, batch, edge_attr, edge_atten=None):
+        return self.get_pred_from_emb(self.get_emb(x, edge_index, batch, edge_attr, edge_atten), batch)
+
+
+class Criterion(nn.Module):
+    """src/utils/get_model.py:19-34."""
+
+    def __init__(self, num_class, multi_label):
+        super().__init__()
+        self.num_class, self.multi_label = num_class, multi_label
+
+    def forward(self, logits, targets):
+        if self.num_class == 2 and not self.multi_label:
+            return F.binary_cross_entropy_with_logits(logits, targets.float())
+        if self.num_class > 2 and not self.multi_label:
+            return F.cross_entropy(logits, targets.long())
+        is_labeled = targets == targets
+        return F.binary_cross_entropy_with_logits(logits[is_labeled], targets[is_labeled].float())
+
+
+class GSAT(nn.Module):
+    """Vanilla GSAT step, example/gsat.py:12-117 (``forward_pass``), with explicit randomness."""
+
+    def __init__(self, clf, extractor, criterion, learn_edge_att=True, final_r=0.7, decay_interval=10, decay_r=0.1):
+        super().__init__()
+        self.clf, self.extractor, self.criterion = clf, extractor, criterion
+        self.learn_edge_att = learn_edge_att
+        self.final_r, self.decay_interval, self.decay_r = final_r, decay_interval, decay_r
+
+    def forward_pass(self, data, epoch, training, u=None, masks=None):
+        N = data.x.shape[0]
+        emb = self.clf.get_emb(data.x, data.edge_index, batch=data.batch, edge_attr=data.edge_attr)      # :75
+        att_log_logits = self.extractor(emb, data.edge_index, data.batch, masks=masks)                  # :76
+        att = ops.concrete_sample(att_log_logits, u, training)                                          # :77
+        if self.learn_edge_att:
+            if bk.is_undirected(data.edge_index, N):                                                    # :80
+                rev = torch.from_numpy(bk.reverse_edge_perm(data.edge_index, N))
+                edge_att = ops.symmetrise(att, rev)                                                     # :81-83
+            else:
+                edge_att = att
+        else:
+            edge_att = ops.lift_node_att_to_edge_att(att, data.edge_index)                              # :87
+        clf_logits = self.clf(data.x, data.edge_index, data.batch, edge_attr=data.edge_attr, edge_atten=edge_att)   # :89
+        pred_loss = self.criterion(clf_logits, data.y)                                                  # :28
+        r = ops.get_r(self.decay_interval, self.decay_r, epoch, final_r=self.final_r)                   # :30
+        info = ops.info_loss(att, r)                                                                    # :31
+        loss = pred_loss + info
+        loss_dict = {"loss": loss.item(), "pred": pred_loss.item(), "info": info.item()}
+        return edge_att, loss, loss_dict, clf_logits, dict(emb=emb, att_log_logits=att_log_logits, att=att)
