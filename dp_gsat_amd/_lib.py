@@ -28,6 +28,8 @@ SIGNATURES = {
     "gsat_gather_i64": (INT, [P, P, I64, P, P]),
     "gsat_aggr_sum_fwd": (INT, [P, P, P, P, P, P, P, I64, I64, F32, P, P]),
     "gsat_aggr_sum_bwd": (INT, [P, P, P, P, P, P, P, I64, I64, F32, P, P, P, P]),
+    "gsat_pna_fwd": (INT, [P, P, P, P, P, P, I64, I64, P, INT, P, INT, F32, F32, P, P]),
+    "gsat_pna_bwd": (INT, [P, P, P, P, P, P, P, I64, I64, P, INT, P, INT, F32, F32, P, P, P, P, P]),
     "gsat_segment_pool_fwd": (INT, [P, P, I64, I64, INT, P, P]),
     "gsat_segment_pool_bwd": (INT, [P, P, I64, I64, INT, P, P]),
 }

@@ -100,3 +100,70 @@ class SegmentPool(torch.autograd.Function):
 
 def segment_pool(x, segments, mean: bool):
     return SegmentPool.apply(x, segments.node_ptr, segments.G, mean)
+
+
+AGGREGATOR_CODES = {"sum": 0, "mean": 1, "min": 2, "max": 3, "var": 4, "std": 5}
+SCALER_CODES = {"identity": 0, "amplification": 1, "attenuation": 2, "linear": 3, "inverse_linear": 4}
+
+
+class PnaAggregate(torch.autograd.Function):
+    """[N, S*A*F] multi-aggregation of att_e * [x_i || x_j (|| edge_emb_e)].
+
+    replaces: PNAConvSimple.message/aggregate (src/models/conv_layers.py:166-185, 193-259)."""
+
+    @staticmethod
+    def forward(ctx, x, att, edge_emb, index: BatchIndex, aggr_codes, scaler_codes, avg_lin: float, avg_log: float):
+        import ctypes
+        x = _f32c(x)
+        attf = _flat_att(att, index.E)
+        edge_emb = _f32c(edge_emb)
+        N, H = x.shape
+        if N != index.N:
+            raise ValueError(f"x has {N} rows but the index was built for {index.N} nodes")
+        if edge_emb is not None and tuple(edge_emb.shape) != (index.E, H):
+            raise ValueError("edge_attr embedding must be [E, hidden]")
+        A, S = len(aggr_codes), len(scaler_codes)
+        F = (3 if edge_emb is not None else 2) * H
+        a_arr = (ctypes.c_int32 * A)(*aggr_codes)
+        s_arr = (ctypes.c_int32 * S)(*scaler_codes)
+        out = torch.empty(N, S * A * F, dtype=torch.float32, device=x.device)
+        call("gsat_pna_fwd", ptr(x), ptr(attf), ptr(edge_emb), ptr(index.rowptr_dst), ptr(index.src_by_dst),
+             ptr(index.eid_by_dst), N, H, a_arr, A, s_arr, S, float(avg_lin), float(avg_log), ptr(out), stream())
+        ctx.save_for_backward(x, attf, edge_emb)
+        ctx.index = index
+        ctx.cfg = (tuple(aggr_codes), tuple(scaler_codes), float(avg_lin), float(avg_log))
+        ctx.att_shape = None if att is None else att.shape
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        import ctypes
+        x, attf, edge_emb = ctx.saved_tensors
+        index = ctx.index
+        aggr_codes, scaler_codes, avg_lin, avg_log = ctx.cfg
+        dout = _f32c(dout)
+        N, H = x.shape
+        A, S = len(aggr_codes), len(scaler_codes)
+        a_arr = (ctypes.c_int32 * A)(*aggr_codes)
+        s_arr = (ctypes.c_int32 * S)(*scaler_codes)
+        need_att = attf is not None and ctx.needs_input_grad[1]
+        need_ee = edge_emb is not None and ctx.needs_input_grad[2]
+        dev = x.device
+        dx_self = torch.empty_like(x)
+        dmsg = torch.empty(max(index.E, 1), H, dtype=torch.float32, device=dev)[: index.E]
+        datt = torch.empty(index.E, dtype=torch.float32, device=dev) if need_att else None
+        dee = torch.empty_like(edge_emb) if need_ee else None
+        call("gsat_pna_bwd", ptr(x), ptr(attf), ptr(edge_emb), ptr(dout), ptr(index.rowptr_dst), ptr(index.src_by_dst),
+             ptr(index.eid_by_dst), N, H, a_arr, A, s_arr, S, avg_lin, avg_log, ptr(dx_self), ptr(dmsg), ptr(datt),
+             ptr(dee), stream())
+        # second pass: sum the per-edge gradient rows of every source node through the inverted index
+        dx = torch.empty_like(x)
+        call("gsat_aggr_sum_fwd", ptr(dmsg), ptr(dx_self), None, None, ptr(index.rowptr_src),
+             ptr(index.slot_dst_of_srcslot), None, N, H, 1.0, ptr(dx), stream())
+        return dx, (datt.view(ctx.att_shape) if need_att else None), dee, None, None, None, None, None
+
+
+def pna_aggregate(x, index, att, edge_emb, aggregators, scalers, avg_deg):
+    a = [AGGREGATOR_CODES[k] for k in aggregators]
+    s = [SCALER_CODES[k] for k in scalers]
+    return PnaAggregate.apply(x, att, edge_emb, index, a, s, avg_deg["lin"], avg_deg["log"])

@@ -112,6 +112,53 @@ int gsat_aggr_sum_bwd(const float* x, const float* att, const float* edge_emb, c
                       int64_t num_rows, int64_t H, float self_coef, float* dx, float* datt,
                       float* dedge_emb, void* stream);
 
+/* ============================ masked message passing: PNA multi-aggregation ================== */
+
+/* aggregator codes (order of `aggregators` = order of the YAML list, src/configs/PNA-*.yml) */
+#define GSAT_AGG_SUM 0
+#define GSAT_AGG_MEAN 1
+#define GSAT_AGG_MIN 2
+#define GSAT_AGG_MAX 3
+#define GSAT_AGG_VAR 4
+#define GSAT_AGG_STD 5
+/* scaler codes (src/models/conv_layers.py:229-259) */
+#define GSAT_SCALE_IDENTITY 0
+#define GSAT_SCALE_AMPLIFICATION 1
+#define GSAT_SCALE_ATTENUATION 2
+#define GSAT_SCALE_LINEAR 3
+#define GSAT_SCALE_INVERSE_LINEAR 4
+
+/*
+ * out[i, ((s*A + a)*F + p*H) : +H] = scaler_s(deg_i) * aggr_a over in-edges k of row i of
+ *   m_k = att_k * [ x[i,:] || x[col[k],:] (|| edge_emb[eid[k],:]) ],   F = 2H (3H with edge_emb)
+ * mean: count clamped >= 1; min/max: 0 for empty rows; var = mean(m^2) - mean(m)^2;
+ * std = sqrt(relu(var) + 1e-5) (so sqrt(1e-5) for empty rows); deg_i = unweighted in-degree.
+ * replaces: PNAConvSimple.message + aggregate up to `post_nn`
+ *           (src/models/conv_layers.py:160-185, aggregators :193-226, scalers :229-259).
+ * aggregators / scalers are HOST int32 arrays (1..8 entries).  H % 4 == 0, H <= 256.
+ */
+int gsat_pna_fwd(const float* x, const float* att, const float* edge_emb, const int32_t* rowptr,
+                 const int32_t* col, const int32_t* eid, int64_t num_rows, int64_t H,
+                 const int32_t* aggregators, int num_aggregators, const int32_t* scalers, int num_scalers,
+                 float avg_deg_lin, float avg_deg_log, float* out, void* stream);
+
+/*
+ * Backward, destination-row pass.  For every in-edge slot k (CSR-by-destination order):
+ *   dmsg[k,:]           = gradient w.r.t. the gathered row x[col[k],:]      ([E,H], slot order)
+ *   datt[eid[k]]        = gradient w.r.t. att of that edge                    (nullable)
+ *   dedge_emb[eid[k],:] = gradient w.r.t. edge_emb                            (nullable)
+ *   dx_self[i,:]        = gradient w.r.t. x[i,:] through the x_i third of the message
+ * min/max route to the FIRST slot attaining the extremum (torch-scatter CPU rule); std's relu has
+ * zero slope at var <= 0.  The caller finishes dx[j,:] = dx_self[j,:] + sum_{slots of source j}
+ * dmsg[slot,:] with gsat_aggr_sum_fwd over the by-source CSR (col = slot map, att = NULL).
+ * replaces: autograd backward of the PNA scatter passes (example/trainer.py:34).
+ */
+int gsat_pna_bwd(const float* x, const float* att, const float* edge_emb, const float* dout,
+                 const int32_t* rowptr, const int32_t* col, const int32_t* eid, int64_t num_rows, int64_t H,
+                 const int32_t* aggregators, int num_aggregators, const int32_t* scalers, int num_scalers,
+                 float avg_deg_lin, float avg_deg_log, float* dx_self, float* dmsg, float* datt,
+                 float* dedge_emb, void* stream);
+
 /* ================================ global pools / segment ops ================================ */
 
 /*
