@@ -30,9 +30,42 @@ SIGNATURES = {
     "gsat_aggr_sum_bwd": (INT, [P, P, P, P, P, P, P, I64, I64, F32, P, P, P, P]),
     "gsat_pna_fwd": (INT, [P, P, P, P, P, P, I64, I64, P, INT, P, INT, F32, F32, P, P]),
     "gsat_pna_bwd": (INT, [P, P, P, P, P, P, P, I64, I64, P, INT, P, INT, F32, F32, P, P, P, P, P]),
+    "gsat_attn_bwd_workspace_bytes": (SZ, [P]),
+    "gsat_attn_fwd": (INT, [P, P]),
+    "gsat_attn_bwd": (INT, [P, P, P]),
+    "gsat_instance_norm_fwd": (INT, [P, P, P, P, I64, I64, I64, P, P, P]),
+    "gsat_instance_norm_bwd": (INT, [P, P, P, P, P, P, I64, I64, I64, P, P, P]),
+    "gsat_philox_keep_mask": (INT, [U64, I32, I64, I64, F32, P, P]),
+    "gsat_sample_fwd": (INT, [P, P, INT, F32, F32, I64, P, P]),
+    "gsat_sample_bwd": (INT, [P, P, F32, I64, P, P]),
+    "gsat_lift_fwd": (INT, [P, P, P, I64, P, P]),
+    "gsat_lift_bwd": (INT, [P, P, P, P, P, P, P, P, I64, P, P]),
+    "gsat_symmetrise": (INT, [P, P, I64, P, P]),
+    "gsat_info_loss_fwd": (INT, [P, P, F32, I64, P, P, P]),
+    "gsat_info_loss_bwd": (INT, [P, P, F32, P, I64, P, P]),
+    "gsat_narrow_i64": (INT, [P, I64, P, P]),
     "gsat_segment_pool_fwd": (INT, [P, P, I64, I64, INT, P, P]),
     "gsat_segment_pool_bwd": (INT, [P, P, I64, I64, INT, P, P]),
 }
+
+
+
+class AttnArgs(ctypes.Structure):
+    """mirror of `gsat_attn_args` (include/gsat_hip.h)."""
+    _fields_ = [("M", I64), ("N", I64), ("G", I64), ("H", I32), ("C1", I32), ("C2", I32), ("edge_mode", I32),
+                ("training", I32), ("p_drop", F32), ("seed", U64),
+                ("src", P), ("dst", P), ("seg_ptr", P), ("seg_order", P), ("row_seg", P),
+                ("W1", P), ("b1", P), ("W2", P), ("b2", P), ("W3", P), ("b3", P),
+                ("emb", P), ("mask1", P), ("mask2", P), ("u", P),
+                ("P", P), ("Q", P), ("a1", P), ("h2", P), ("stats", P), ("logits", P), ("att", P)]
+
+
+class AttnGrads(ctypes.Structure):
+    """mirror of `gsat_attn_grads` (include/gsat_hip.h)."""
+    _fields_ = [("dlogits", P), ("datt", P), ("rowptr_src", P), ("eid_by_src", P), ("rowptr_dst", P), ("eid_by_dst", P),
+                ("demb", P), ("dW1", P), ("db1", P), ("dW2", P), ("db2", P), ("dW3", P), ("db3", P),
+                ("workspace", P), ("workspace_bytes", SZ)]
+
 
 _lib = None
 

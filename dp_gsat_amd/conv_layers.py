@@ -1,0 +1,82 @@
+"""Conv operators with the reference's call signature ``conv(x, edge_index, edge_attr=None, edge_atten=None)``.
+
+Message passing (gather, mask, reduce, and its backward) runs in the HIP kernels behind
+:mod:`dp_gsat_amd.ops`; the dense node update stays a library GEMM (torch -> hipBLASLt).
+"""
+from __future__ import annotations
+
+from typing import Dict, List
+
+import torch
+import torch.nn as nn
+
+from .graph_index import get_index
+from .ops import masked_sum_aggregate, pna_aggregate
+
+
+def _index_of(edge_index, x, index):
+    return index if index is not None else get_index(edge_index, x.shape[0])
+
+
+class GINConv(nn.Module):
+    """out = nn((1+eps) x_i + sum_j a_ji x_j)   (src/models/conv_layers.py:14-34; eps is a 0 buffer)."""
+
+    def __init__(self, nn_: nn.Module, eps: float = 0.0):
+        super().__init__()
+        self.nn = nn_
+        self.register_buffer("eps", torch.Tensor([eps]))
+        self._eps0 = float(eps)
+
+    def forward(self, x, edge_index, edge_attr=None, edge_atten=None, size=None, index=None):
+        out = masked_sum_aggregate(x, _index_of(edge_index, x, index), edge_atten, None, self._eps0)
+        return self.nn(out)
+
+
+class GINEConv(nn.Module):
+    """out = nn((1+eps) x_i + sum_j a_ji relu(x_j + lin(e_ji)))   (src/models/conv_layers.py:37-66)."""
+
+    def __init__(self, nn_: nn.Module, eps: float = 0.0, edge_dim=None, in_channels=None):
+        super().__init__()
+        self.nn = nn_
+        self.register_buffer("eps", torch.Tensor([eps]))
+        self._eps0 = float(eps)
+        if in_channels is None:
+            in_channels = next(m for m in nn_.modules() if isinstance(m, nn.Linear)).in_features
+        self.lin = nn.Linear(edge_dim, in_channels) if edge_dim is not None else None
+
+    def forward(self, x, edge_index, edge_attr=None, edge_atten=None, size=None, index=None):
+        if self.lin is None and x.size(-1) != edge_attr.size(-1):
+            raise ValueError("Node and edge feature dimensionalities do not match. Consider setting the "
+                             "'edge_dim' attribute of 'GINEConv'")
+        edge_emb = self.lin(edge_attr) if self.lin is not None else edge_attr
+        out = masked_sum_aggregate(x, _index_of(edge_index, x, index), edge_atten, edge_emb, self._eps0)
+        return self.nn(out)
+
+
+class PNAConvSimple(nn.Module):
+    """post_nn(scalers x aggregators of a_ji [x_i || x_j (|| e_ji)])   (src/models/conv_layers.py:96-191)."""
+
+    def __init__(self, in_channels: int, out_channels: int, aggregators: List[str], scalers: List[str],
+                 deg: torch.Tensor, post_layers: int = 1):
+        super().__init__()
+        self.in_channels, self.out_channels = in_channels, out_channels
+        self.aggregators, self.scalers = list(aggregators), list(scalers)
+        self.F_in, self.F_out = in_channels, out_channels
+        deg = deg.to(torch.float)
+        # statistics of the histogram VALUES, as the reference computes them (conv_layers.py:141-146)
+        self.avg_deg: Dict[str, float] = {"lin": deg.mean().item(), "log": (deg + 1).log().mean().item(),
+                                          "exp": deg.exp().mean().item()}
+        modules = [nn.Linear(len(aggregators) * len(scalers) * self.F_in, self.F_out)]
+        for _ in range(post_layers - 1):
+            modules += [nn.ReLU(), nn.Linear(self.F_out, self.F_out)]
+        self.post_nn = nn.Sequential(*modules)
+
+    def forward(self, x, edge_index, edge_attr=None, edge_atten=None, index=None):
+        agg = pna_aggregate(x, _index_of(edge_index, x, index), edge_atten, edge_attr, self.aggregators,
+                            self.scalers, self.avg_deg)
+        if agg.shape[1] != self.post_nn[0].in_features:
+            raise ValueError(f"PNAConvSimple was built for F_in={self.F_in} but the message is {agg.shape[1]} wide")
+        return self.post_nn(agg)
+
+    def __repr__(self):
+        return f"{self.__class__.__name__}({self.in_channels}, {self.out_channels})"

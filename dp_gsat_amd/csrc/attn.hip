@@ -1,0 +1,650 @@
+// Attention extractor: Linear -> per-graph InstanceNorm -> ReLU -> Dropout (x2) -> Linear(.,1) -> concrete
+// sampler, forward and backward (example/gsat.py:94-103,131-139; src/utils/get_model.py:47-68).
+//
+// Staging (round-1 form; the ABI hides it):
+//   * edge mode evaluates layer 1 on NODES: P = emb W1a^T, Q = emb W1b^T, h1_e = P[src_e]+Q[dst_e]+b1.
+//     The [E,2H] concat, the E-row first GEMM and h1 itself are never materialised; the InstanceNorm
+//     statistics kernel and the a1 producer recompute h1 from two gathered rows.
+//   * dense contractions (P/Q, h2 = a1 W2^T and their gradients) go through rocBLAS sgemm (true fp32
+//     MFMA, atomics off); everything else is hand-written: segmented statistics, normalise + ReLU +
+//     Philox dropout, the head (C2 -> 1 dot + sampler), InstanceNorm backward, deterministic column sums.
+//   * all reductions run in a fixed order (no float atomics): results are bitwise reproducible.
+#include "common.h"
+#include <rocblas/rocblas.h>
+
+namespace gsat {
+
+constexpr float IN_EPS = 1e-5f;
+constexpr int SB = 256;          // threads per block in the segmented kernels: 16 row slots x 16 lanes
+constexpr int SB_LANES = 16;     // lanes per row slot, one float4 each -> 64 channels per block
+constexpr int SB_SLOTS = 16;
+
+// ------------------------------------------------------------------------------------------------
+// rocBLAS plumbing: row-major C[M,N] = alpha * op(A) op(B) + beta * C
+// ------------------------------------------------------------------------------------------------
+static rocblas_handle blas_handle() {
+    static thread_local rocblas_handle h = nullptr;
+    if (!h) {
+        if (rocblas_create_handle(&h) != rocblas_status_success) { h = nullptr; return nullptr; }
+        rocblas_set_atomics_mode(h, rocblas_atomics_not_allowed);
+        rocblas_set_pointer_mode(h, rocblas_pointer_mode_host);
+    }
+    return h;
+}
+
+static int gemm_rm(hipStream_t stream, bool ta, bool tb, int64_t M, int64_t N, int64_t K, float alpha, const float* A,
+                   int64_t lda, const float* B, int64_t ldb, float beta, float* C, int64_t ldc) {
+    if (M == 0 || N == 0) return GSAT_OK;
+    rocblas_handle h = blas_handle();
+    GSAT_REQUIRE(h, GSAT_ERR_BLAS, "rocblas_create_handle failed");
+    GSAT_REQUIRE(rocblas_set_stream(h, stream) == rocblas_status_success, GSAT_ERR_BLAS, "rocblas_set_stream failed");
+    // row-major X is column-major X^T:  C^T = op(B)^T op(A)^T
+    rocblas_status st = rocblas_sgemm(h, tb ? rocblas_operation_transpose : rocblas_operation_none,
+                                      ta ? rocblas_operation_transpose : rocblas_operation_none, (rocblas_int)N, (rocblas_int)M,
+                                      (rocblas_int)K, &alpha, B, (rocblas_int)ldb, A, (rocblas_int)lda, &beta, C, (rocblas_int)ldc);
+    GSAT_REQUIRE(st == rocblas_status_success, GSAT_ERR_BLAS, "rocblas_sgemm failed with status %d", (int)st);
+    return GSAT_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// pre-activation sources: dense rows (node mode / layer 2) or P[src]+Q[dst] (edge mode layer 1)
+// ------------------------------------------------------------------------------------------------
+template <bool EDGE>
+struct PreAct {
+    const float* P; const float* Q; const float* bias; const int32_t* src; const int32_t* dst; int C;
+    __device__ __forceinline__ float4 load(int row, int c) const {
+        float4 b = bias ? ld4(bias + c) : f4zero();
+        float4 v;
+        if (EDGE) {
+            float4 p = ld4(P + (size_t)src[row] * C + c);
+            float4 q = ld4(Q + (size_t)dst[row] * C + c);
+            v = make_float4(p.x + q.x, p.y + q.y, p.z + q.z, p.w + q.w);
+        } else {
+            v = ld4(P + (size_t)row * C + c);
+        }
+        return make_float4(v.x + b.x, v.y + b.y, v.z + b.z, v.w + b.w);
+    }
+};
+
+__device__ __forceinline__ float4 keep4(const float* mask, uint64_t seed, int layer, int row, int c, int C, float p, bool training) {
+    if (!training || p <= 0.f) return make_float4(1.f, 1.f, 1.f, 1.f);
+    if (mask) return ld4(mask + (size_t)row * C + c);
+    uint4 r = philox4x32(seed, (uint32_t)row, (uint32_t)(c >> 2), (uint32_t)layer, 0x5A17u);
+    const float k = 1.0f / 16777216.0f;
+    return make_float4((float)(r.x >> 8) * k >= p ? 1.f : 0.f, (float)(r.y >> 8) * k >= p ? 1.f : 0.f,
+                       (float)(r.z >> 8) * k >= p ? 1.f : 0.f, (float)(r.w >> 8) * k >= p ? 1.f : 0.f);
+}
+
+// Sum a float4 per (slot, lane) over the 16 row slots in fixed order; result valid in slot 0.
+__device__ __forceinline__ float4 slot_reduce(float4 v, float4 (*sm)[SB_LANES], int slot, int lane) {
+    __syncthreads();
+    sm[slot][lane] = v;
+    __syncthreads();
+    float4 r = f4zero();
+    if (slot == 0) {
+#pragma unroll
+        for (int s = 0; s < SB_SLOTS; ++s) {
+            float4 t = sm[s][lane];
+            r.x += t.x; r.y += t.y; r.z += t.z; r.w += t.w;
+        }
+    }
+    return r;
+}
+
+// ------------------------------------------------------------------------------------------------
+// per-graph, per-channel InstanceNorm statistics: grid (G, ceil(C/64)); two passes over the segment
+// (mean, then variance of the centred values -- the reference's order), second pass is L2-hot.
+// ------------------------------------------------------------------------------------------------
+template <bool EDGE>
+__global__ __launch_bounds__(SB) void k_seg_stats(PreAct<EDGE> pre, const int32_t* __restrict__ seg_ptr,
+                                                  const int32_t* __restrict__ order, float* __restrict__ mean_out,
+                                                  float* __restrict__ rstd_out) {
+    __shared__ float4 sm[SB_SLOTS][SB_LANES];
+    __shared__ float4 bc[SB_LANES];
+    const int g = blockIdx.x;
+    const int lane = threadIdx.x % SB_LANES, slot = threadIdx.x / SB_LANES;
+    const int c = (blockIdx.y * SB_LANES + lane) * 4;
+    const int C = pre.C;
+    const bool on = c < C;
+    const int beg = seg_ptr[g], end = seg_ptr[g + 1];
+    const float inv_n = 1.f / (float)max(end - beg, 1);
+    float4 acc = f4zero();
+    if (on)
+        for (int r = beg + slot; r < end; r += SB_SLOTS) {
+            float4 h = pre.load(order ? order[r] : r, c);
+            acc.x += h.x; acc.y += h.y; acc.z += h.z; acc.w += h.w;
+        }
+    float4 tot = slot_reduce(acc, sm, slot, lane);
+    if (slot == 0) bc[lane] = make_float4(tot.x * inv_n, tot.y * inv_n, tot.z * inv_n, tot.w * inv_n);
+    __syncthreads();
+    const float4 mu = bc[lane];
+    acc = f4zero();
+    if (on)
+        for (int r = beg + slot; r < end; r += SB_SLOTS) {
+            float4 h = pre.load(order ? order[r] : r, c);
+            float dx = h.x - mu.x, dy = h.y - mu.y, dz = h.z - mu.z, dw = h.w - mu.w;
+            acc.x = fmaf(dx, dx, acc.x); acc.y = fmaf(dy, dy, acc.y); acc.z = fmaf(dz, dz, acc.z); acc.w = fmaf(dw, dw, acc.w);
+        }
+    tot = slot_reduce(acc, sm, slot, lane);
+    if (slot == 0 && on) {
+        st4(mean_out + (size_t)g * C + c, mu);
+        st4(rstd_out + (size_t)g * C + c,
+            make_float4(1.f / sqrtf(tot.x * inv_n + IN_EPS), 1.f / sqrtf(tot.y * inv_n + IN_EPS),
+                        1.f / sqrtf(tot.z * inv_n + IN_EPS), 1.f / sqrtf(tot.w * inv_n + IN_EPS)));
+    }
+}
+
+// a[m,c] = relu((h - mean) * rstd) * keep / (1-p)     (elementwise over [M, C]); RELU=false: plain norm
+template <bool EDGE, bool RELU>
+__global__ void k_norm_apply(PreAct<EDGE> pre, const int32_t* __restrict__ row_seg, const float* __restrict__ mean,
+                             const float* __restrict__ rstd, const float* __restrict__ mask, uint64_t seed, int layer,
+                             float p, int training, int64_t M, float* __restrict__ out) {
+    const int C = pre.C, C4 = C >> 2;
+    const float sc = (training && p > 0.f) ? 1.f / (1.f - p) : 1.f;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < M * C4; i += (int64_t)gridDim.x * blockDim.x) {
+        const int m = (int)(i / C4), c = (int)(i % C4) * 4;
+        const int g = row_seg[m];
+        float4 h = pre.load(m, c);
+        float4 mu = ld4(mean + (size_t)g * C + c), rs = ld4(rstd + (size_t)g * C + c);
+        float4 y = make_float4((h.x - mu.x) * rs.x, (h.y - mu.y) * rs.y, (h.z - mu.z) * rs.z, (h.w - mu.w) * rs.w);
+        if (RELU) {
+            float4 k = keep4(mask, seed, layer, m, c, C, p, training != 0);
+            y = make_float4(fmaxf(y.x, 0.f) * k.x * sc, fmaxf(y.y, 0.f) * k.y * sc, fmaxf(y.z, 0.f) * k.z * sc, fmaxf(y.w, 0.f) * k.w * sc);
+        }
+        st4(out + (size_t)m * C + c, y);
+    }
+}
+
+// head: z[m] = sum_c relu(norm(h2+b2))*keep/(1-p)*w3[c] + b3 ; att = sigmoid(z (+ logit noise))
+template <int LPR>
+__global__ __launch_bounds__(256) void k_head_fwd(const float* __restrict__ h2, const float* __restrict__ b2,
+                                                  const int32_t* __restrict__ row_seg, const float* __restrict__ mean,
+                                                  const float* __restrict__ rstd, const float* __restrict__ mask, uint64_t seed,
+                                                  float p, int training, const float* __restrict__ w3, const float* __restrict__ b3,
+                                                  const float* __restrict__ u, int64_t M, int C, float* __restrict__ logits,
+                                                  float* __restrict__ att) {
+    const int lane = threadIdx.x % LPR;
+    const float sc = (training && p > 0.f) ? 1.f / (1.f - p) : 1.f;
+    PreAct<false> pre{h2, nullptr, b2, nullptr, nullptr, C};
+    for (int64_t m = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) / LPR; m < M; m += (int64_t)gridDim.x * blockDim.x / LPR) {
+        const int g = row_seg[m];
+        float acc = 0.f;
+        for (int c = lane * 4; c < C; c += LPR * 4) {
+            float4 h = pre.load((int)m, c);
+            float4 mu = ld4(mean + (size_t)g * C + c), rs = ld4(rstd + (size_t)g * C + c);
+            float4 k = keep4(mask, seed, 2, (int)m, c, C, p, training != 0);
+            float4 w = ld4(w3 + c);
+            acc = fmaf(fmaxf((h.x - mu.x) * rs.x, 0.f) * k.x * sc, w.x, acc);
+            acc = fmaf(fmaxf((h.y - mu.y) * rs.y, 0.f) * k.y * sc, w.y, acc);
+            acc = fmaf(fmaxf((h.z - mu.z) * rs.z, 0.f) * k.z * sc, w.z, acc);
+            acc = fmaf(fmaxf((h.w - mu.w) * rs.w, 0.f) * k.w * sc, w.w, acc);
+        }
+        acc = group_sum<LPR>(acc);
+        if (lane == 0) {
+            const float z = acc + b3[0];
+            logits[m] = z;
+            if (att) {
+                float t = z;
+                if (training && u) { float uu = u[m]; t = z + (logf(uu) - logf(1.0f - uu)); }
+                att[m] = 1.f / (1.f + expf(-t));
+            }
+        }
+    }
+}
+
+// dz[m] = dlogits[m] + datt[m] * att[m] * (1 - att[m])
+__global__ void k_dz(const float* __restrict__ dlogits, const float* __restrict__ datt, const float* __restrict__ att, int64_t M,
+                     float* __restrict__ dz) {
+    int64_t m = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (m >= M) return;
+    float v = dlogits ? dlogits[m] : 0.f;
+    if (datt) { float a = att[m]; v = fmaf(datt[m], a * (1.f - a), v); }
+    dz[m] = v;
+}
+
+// Backward statistics of layer 2 (through the head): per (graph, channel)
+//   S1 = mean_r dy2 , S2 = mean_r dy2*yhat2 , dw3 partial = sum_r dz * a2
+__global__ __launch_bounds__(SB) void k_head_bwd_stats(const float* __restrict__ h2, const float* __restrict__ b2,
+                                                       const int32_t* __restrict__ seg_ptr, const int32_t* __restrict__ order,
+                                                       const float* __restrict__ mean, const float* __restrict__ rstd,
+                                                       const float* __restrict__ mask, uint64_t seed, float p, int training,
+                                                       const float* __restrict__ w3, const float* __restrict__ dz, int C,
+                                                       float* __restrict__ S1, float* __restrict__ S2, float* __restrict__ dw3p) {
+    __shared__ float4 sm[SB_SLOTS][SB_LANES];
+    const int g = blockIdx.x;
+    const int lane = threadIdx.x % SB_LANES, slot = threadIdx.x / SB_LANES;
+    const int c = (blockIdx.y * SB_LANES + lane) * 4;
+    const bool on = c < C;
+    const int beg = seg_ptr[g], end = seg_ptr[g + 1];
+    const float inv_n = 1.f / (float)max(end - beg, 1);
+    const float sc = (training && p > 0.f) ? 1.f / (1.f - p) : 1.f;
+    PreAct<false> pre{h2, nullptr, b2, nullptr, nullptr, C};
+    float4 a1 = f4zero(), a2 = f4zero(), a3 = f4zero();
+    if (on) {
+        const float4 mu = ld4(mean + (size_t)g * C + c), rs = ld4(rstd + (size_t)g * C + c), w = ld4(w3 + c);
+        for (int r = beg + slot; r < end; r += SB_SLOTS) {
+            const int m = order ? order[r] : r;
+            const float d = dz[m];
+            float4 h = pre.load(m, c);
+            float4 k = keep4(mask, seed, 2, m, c, C, p, training != 0);
+            float4 y = make_float4((h.x - mu.x) * rs.x, (h.y - mu.y) * rs.y, (h.z - mu.z) * rs.z, (h.w - mu.w) * rs.w);
+            float4 dy = make_float4(y.x > 0.f ? d * w.x * k.x * sc : 0.f, y.y > 0.f ? d * w.y * k.y * sc : 0.f,
+                                    y.z > 0.f ? d * w.z * k.z * sc : 0.f, y.w > 0.f ? d * w.w * k.w * sc : 0.f);
+            a1.x += dy.x; a1.y += dy.y; a1.z += dy.z; a1.w += dy.w;
+            a2.x = fmaf(dy.x, y.x, a2.x); a2.y = fmaf(dy.y, y.y, a2.y); a2.z = fmaf(dy.z, y.z, a2.z); a2.w = fmaf(dy.w, y.w, a2.w);
+            a3.x = fmaf(d, fmaxf(y.x, 0.f) * k.x * sc, a3.x); a3.y = fmaf(d, fmaxf(y.y, 0.f) * k.y * sc, a3.y);
+            a3.z = fmaf(d, fmaxf(y.z, 0.f) * k.z * sc, a3.z); a3.w = fmaf(d, fmaxf(y.w, 0.f) * k.w * sc, a3.w);
+        }
+    }
+    float4 t1 = slot_reduce(a1, sm, slot, lane);
+    float4 t2 = slot_reduce(a2, sm, slot, lane);
+    float4 t3 = slot_reduce(a3, sm, slot, lane);
+    if (slot == 0 && on) {
+        st4(S1 + (size_t)g * C + c, make_float4(t1.x * inv_n, t1.y * inv_n, t1.z * inv_n, t1.w * inv_n));
+        st4(S2 + (size_t)g * C + c, make_float4(t2.x * inv_n, t2.y * inv_n, t2.z * inv_n, t2.w * inv_n));
+        st4(dw3p + (size_t)g * C + c, t3);
+    }
+}
+
+// dh2[m,c] = rstd2 * (dy2 - S1 - yhat2 * S2)
+__global__ void k_dh2(const float* __restrict__ h2, const float* __restrict__ b2, const int32_t* __restrict__ row_seg,
+                      const float* __restrict__ mean, const float* __restrict__ rstd, const float* __restrict__ mask, uint64_t seed,
+                      float p, int training, const float* __restrict__ w3, const float* __restrict__ dz,
+                      const float* __restrict__ S1, const float* __restrict__ S2, int64_t M, int C, float* __restrict__ dh2) {
+    const int C4 = C >> 2;
+    const float sc = (training && p > 0.f) ? 1.f / (1.f - p) : 1.f;
+    PreAct<false> pre{h2, nullptr, b2, nullptr, nullptr, C};
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < M * C4; i += (int64_t)gridDim.x * blockDim.x) {
+        const int m = (int)(i / C4), c = (int)(i % C4) * 4;
+        const int g = row_seg[m];
+        const float d = dz[m];
+        float4 h = pre.load(m, c);
+        float4 mu = ld4(mean + (size_t)g * C + c), rs = ld4(rstd + (size_t)g * C + c), w = ld4(w3 + c);
+        float4 k = keep4(mask, seed, 2, m, c, C, p, training != 0);
+        float4 s1 = ld4(S1 + (size_t)g * C + c), s2 = ld4(S2 + (size_t)g * C + c);
+        float4 y = make_float4((h.x - mu.x) * rs.x, (h.y - mu.y) * rs.y, (h.z - mu.z) * rs.z, (h.w - mu.w) * rs.w);
+        float4 dy = make_float4(y.x > 0.f ? d * w.x * k.x * sc : 0.f, y.y > 0.f ? d * w.y * k.y * sc : 0.f,
+                                y.z > 0.f ? d * w.z * k.z * sc : 0.f, y.w > 0.f ? d * w.w * k.w * sc : 0.f);
+        st4(dh2 + (size_t)m * C + c, make_float4(rs.x * (dy.x - s1.x - y.x * s2.x), rs.y * (dy.y - s1.y - y.y * s2.y),
+                                                  rs.z * (dy.z - s1.z - y.z * s2.z), rs.w * (dy.w - s1.w - y.w * s2.w)));
+    }
+}
+
+// Backward statistics of layer 1 from (da1, a1):  dy1 = da1*[a1>0]*sc ; yhat1*[a1>0] = a1/sc
+__global__ __launch_bounds__(SB) void k_l1_bwd_stats(const float* __restrict__ da1, const float* __restrict__ a1,
+                                                     const int32_t* __restrict__ seg_ptr, const int32_t* __restrict__ order,
+                                                     float sc, int C, float* __restrict__ S1, float* __restrict__ S2) {
+    __shared__ float4 sm[SB_SLOTS][SB_LANES];
+    const int g = blockIdx.x;
+    const int lane = threadIdx.x % SB_LANES, slot = threadIdx.x / SB_LANES;
+    const int c = (blockIdx.y * SB_LANES + lane) * 4;
+    const bool on = c < C;
+    const int beg = seg_ptr[g], end = seg_ptr[g + 1];
+    const float inv_n = 1.f / (float)max(end - beg, 1);
+    const float inv_sc = 1.f / sc;
+    float4 s1 = f4zero(), s2 = f4zero();
+    if (on)
+        for (int r = beg + slot; r < end; r += SB_SLOTS) {
+            const int m = order ? order[r] : r;
+            float4 d = ld4(da1 + (size_t)m * C + c), a = ld4(a1 + (size_t)m * C + c);
+            float4 dy = make_float4(a.x > 0.f ? d.x * sc : 0.f, a.y > 0.f ? d.y * sc : 0.f, a.z > 0.f ? d.z * sc : 0.f, a.w > 0.f ? d.w * sc : 0.f);
+            s1.x += dy.x; s1.y += dy.y; s1.z += dy.z; s1.w += dy.w;
+            s2.x = fmaf(dy.x, a.x * inv_sc, s2.x); s2.y = fmaf(dy.y, a.y * inv_sc, s2.y);
+            s2.z = fmaf(dy.z, a.z * inv_sc, s2.z); s2.w = fmaf(dy.w, a.w * inv_sc, s2.w);
+        }
+    float4 t1 = slot_reduce(s1, sm, slot, lane);
+    float4 t2 = slot_reduce(s2, sm, slot, lane);
+    if (slot == 0 && on) {
+        st4(S1 + (size_t)g * C + c, make_float4(t1.x * inv_n, t1.y * inv_n, t1.z * inv_n, t1.w * inv_n));
+        st4(S2 + (size_t)g * C + c, make_float4(t2.x * inv_n, t2.y * inv_n, t2.z * inv_n, t2.w * inv_n));
+    }
+}
+
+// dh1[m,c] = rstd1 * (dy1 - S1 - yhat1*S2), written in place over da1 ; yhat1 recomputed from the pre-activation
+template <bool EDGE>
+__global__ void k_dh1(PreAct<EDGE> pre, const int32_t* __restrict__ row_seg, const float* __restrict__ mean,
+                      const float* __restrict__ rstd, const float* __restrict__ a1, float sc, const float* __restrict__ S1,
+                      const float* __restrict__ S2, int64_t M, float* __restrict__ da1_inout) {
+    const int C = pre.C, C4 = C >> 2;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < M * C4; i += (int64_t)gridDim.x * blockDim.x) {
+        const int m = (int)(i / C4), c = (int)(i % C4) * 4;
+        const int g = row_seg[m];
+        float4 h = pre.load(m, c);
+        float4 mu = ld4(mean + (size_t)g * C + c), rs = ld4(rstd + (size_t)g * C + c);
+        float4 y = make_float4((h.x - mu.x) * rs.x, (h.y - mu.y) * rs.y, (h.z - mu.z) * rs.z, (h.w - mu.w) * rs.w);
+        float4 d = ld4(da1_inout + (size_t)m * C + c), a = ld4(a1 + (size_t)m * C + c);
+        float4 dy = make_float4(a.x > 0.f ? d.x * sc : 0.f, a.y > 0.f ? d.y * sc : 0.f, a.z > 0.f ? d.z * sc : 0.f, a.w > 0.f ? d.w * sc : 0.f);
+        float4 s1 = ld4(S1 + (size_t)g * C + c), s2 = ld4(S2 + (size_t)g * C + c);
+        st4(da1_inout + (size_t)m * C + c, make_float4(rs.x * (dy.x - s1.x - y.x * s2.x), rs.y * (dy.y - s1.y - y.y * s2.y),
+                                                        rs.z * (dy.z - s1.z - y.z * s2.z), rs.w * (dy.w - s1.w - y.w * s2.w)));
+    }
+}
+
+// generic InstanceNorm backward from saved y: dx = rstd * (dy - mean(dy) - y*mean(dy*y))
+__global__ __launch_bounds__(SB) void k_in_bwd_stats(const float* __restrict__ y, const float* __restrict__ dy,
+                                                     const int32_t* __restrict__ seg_ptr, const int32_t* __restrict__ order, int C,
+                                                     float* __restrict__ S1, float* __restrict__ S2) {
+    __shared__ float4 sm[SB_SLOTS][SB_LANES];
+    const int g = blockIdx.x;
+    const int lane = threadIdx.x % SB_LANES, slot = threadIdx.x / SB_LANES;
+    const int c = (blockIdx.y * SB_LANES + lane) * 4;
+    const bool on = c < C;
+    const int beg = seg_ptr[g], end = seg_ptr[g + 1];
+    const float inv_n = 1.f / (float)max(end - beg, 1);
+    float4 s1 = f4zero(), s2 = f4zero();
+    if (on)
+        for (int r = beg + slot; r < end; r += SB_SLOTS) {
+            const int m = order ? order[r] : r;
+            float4 d = ld4(dy + (size_t)m * C + c), v = ld4(y + (size_t)m * C + c);
+            s1.x += d.x; s1.y += d.y; s1.z += d.z; s1.w += d.w;
+            s2.x = fmaf(d.x, v.x, s2.x); s2.y = fmaf(d.y, v.y, s2.y); s2.z = fmaf(d.z, v.z, s2.z); s2.w = fmaf(d.w, v.w, s2.w);
+        }
+    float4 t1 = slot_reduce(s1, sm, slot, lane);
+    float4 t2 = slot_reduce(s2, sm, slot, lane);
+    if (slot == 0 && on) {
+        st4(S1 + (size_t)g * C + c, make_float4(t1.x * inv_n, t1.y * inv_n, t1.z * inv_n, t1.w * inv_n));
+        st4(S2 + (size_t)g * C + c, make_float4(t2.x * inv_n, t2.y * inv_n, t2.z * inv_n, t2.w * inv_n));
+    }
+}
+
+__global__ void k_in_bwd_apply(const float* __restrict__ y, const float* __restrict__ dy, const int32_t* __restrict__ row_seg,
+                               const float* __restrict__ rstd, const float* __restrict__ S1, const float* __restrict__ S2,
+                               int64_t M, int C, float* __restrict__ dx) {
+    const int C4 = C >> 2;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < M * C4; i += (int64_t)gridDim.x * blockDim.x) {
+        const int m = (int)(i / C4), c = (int)(i % C4) * 4;
+        const int g = row_seg[m];
+        float4 v = ld4(y + (size_t)m * C + c), d = ld4(dy + (size_t)m * C + c);
+        float4 rs = ld4(rstd + (size_t)g * C + c), s1 = ld4(S1 + (size_t)g * C + c), s2 = ld4(S2 + (size_t)g * C + c);
+        st4(dx + (size_t)m * C + c, make_float4(rs.x * (d.x - s1.x - v.x * s2.x), rs.y * (d.y - s1.y - v.y * s2.y),
+                                                 rs.z * (d.z - s1.z - v.z * s2.z), rs.w * (d.w - s1.w - v.w * s2.w)));
+    }
+}
+
+// Deterministic column sum: out[rb, c] = sum over the rb-th row block; grid (ceil(C/64), RB)
+__global__ __launch_bounds__(SB) void k_colsum(const float* __restrict__ x, int64_t R, int C, int64_t rows_per_block,
+                                               float* __restrict__ out) {
+    __shared__ float4 sm[SB_SLOTS][SB_LANES];
+    const int lane = threadIdx.x % SB_LANES, slot = threadIdx.x / SB_LANES;
+    const int c = (blockIdx.x * SB_LANES + lane) * 4;
+    const int64_t beg = (int64_t)blockIdx.y * rows_per_block, end = min(R, beg + rows_per_block);
+    float4 acc = f4zero();
+    if (c + 3 < C) {
+        for (int64_t r = beg + slot; r < end; r += SB_SLOTS) {
+            float4 v = ld4(x + (size_t)r * C + c);
+            acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
+        }
+    } else if (c < C) {       // ragged tail (C not a multiple of 4, e.g. C == 1)
+        for (int64_t r = beg + slot; r < end; r += SB_SLOTS) {
+            const float* p = x + (size_t)r * C + c;
+            acc.x += p[0];
+            if (c + 1 < C) acc.y += p[1];
+            if (c + 2 < C) acc.z += p[2];
+        }
+    }
+    float4 t = slot_reduce(acc, sm, slot, lane);
+    if (slot == 0 && c < C) {
+        float* o = out + (size_t)blockIdx.y * C + c;
+        o[0] = t.x;
+        if (c + 1 < C) o[1] = t.y;
+        if (c + 2 < C) o[2] = t.z;
+        if (c + 3 < C) o[3] = t.w;
+    }
+}
+
+// Segment sum of dh1 rows through a CSR of edge ids: out[n,:] = sum_{k in row n} dh1[eid[k],:]
+__global__ __launch_bounds__(256) void k_rows_by_eid(const float* __restrict__ rows, const int32_t* __restrict__ rowptr,
+                                                     const int32_t* __restrict__ eid, int N, int C, float* __restrict__ out) {
+    // 64 lanes (one wave) per node row, float4 per lane, loop over column chunks
+    const int lane = threadIdx.x & 63;
+    for (int n = blockIdx.x * 4 + (threadIdx.x >> 6); n < N; n += gridDim.x * 4) {
+        const int beg = rowptr[n], end = rowptr[n + 1];
+        for (int c = lane * 4; c < C; c += 256) {
+            float4 acc = f4zero();
+            for (int k = beg; k < end; ++k) {
+                float4 v = ld4(rows + (size_t)eid[k] * C + c);
+                acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
+            }
+            st4(out + (size_t)n * C + c, acc);
+        }
+    }
+}
+
+__global__ void k_philox_mask(uint64_t seed, int layer, int64_t M, int C, float p, float* __restrict__ keep) {
+    const int C4 = C >> 2;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < M * C4; i += (int64_t)gridDim.x * blockDim.x) {
+        const int m = (int)(i / C4), c = (int)(i % C4) * 4;
+        st4(keep + (size_t)m * C + c, keep4(nullptr, seed, layer, m, c, C, p, true));
+    }
+}
+
+static inline int ew_blocks(int64_t work_items) {
+    int64_t nb = ceil_div(work_items, 256);
+    if (nb > 256 * 32) nb = 256 * 32;
+    return (int)std::max<int64_t>(nb, 1);
+}
+
+static int colsum(hipStream_t stream, const float* x, int64_t R, int C, float* out, float* scratch /* [256*C] */) {
+    if (C <= 0) return GSAT_OK;
+    const int ctiles = (int)ceil_div(C, 64);
+    if (R <= 0) { GSAT_CHECK_HIP(hipMemsetAsync(out, 0, sizeof(float) * C, stream)); return GSAT_OK; }
+    int64_t RB = std::min<int64_t>(256, ceil_div(R, 64));
+    if (RB <= 1) {
+        k_colsum<<<dim3(ctiles, 1), SB, 0, stream>>>(x, R, C, R, out);
+    } else {
+        int64_t rpb = ceil_div(R, RB);
+        RB = ceil_div(R, rpb);
+        k_colsum<<<dim3(ctiles, (unsigned)RB), SB, 0, stream>>>(x, R, C, rpb, scratch);
+        k_colsum<<<dim3(ctiles, 1), SB, 0, stream>>>(scratch, RB, C, RB, out);
+    }
+    GSAT_LAUNCH_CHECK();
+    return GSAT_OK;
+}
+
+static int check_args(const gsat_attn_args* a, const char* who) {
+    GSAT_REQUIRE(a, GSAT_ERR_ARG, "%s: null args", who);
+    GSAT_REQUIRE(a->M >= 0 && a->N >= 0 && a->G >= 0 && a->M < (1ll << 31) && a->N < (1ll << 31), GSAT_ERR_ARG, "%s: bad extents", who);
+    GSAT_REQUIRE(a->H > 0 && a->C1 > 0 && a->C2 > 0 && a->H % 4 == 0 && a->C1 % 4 == 0 && a->C2 % 4 == 0, GSAT_ERR_UNSUPPORTED,
+                 "%s: H, C1, C2 must be positive multiples of 4 (got %d, %d, %d)", who, a->H, a->C1, a->C2);
+    GSAT_REQUIRE(a->p_drop >= 0.f && a->p_drop < 1.f, GSAT_ERR_ARG, "%s: dropout p must be in [0,1)", who);
+    if (a->M == 0) return GSAT_OK;
+    GSAT_REQUIRE(a->emb && a->W1 && a->b1 && a->W2 && a->b2 && a->W3 && a->b3 && a->seg_ptr && a->row_seg, GSAT_ERR_ARG, "%s: null input", who);
+    GSAT_REQUIRE(a->P && a->a1 && a->h2 && a->stats && a->logits, GSAT_ERR_ARG, "%s: null output/saved buffer", who);
+    if (a->edge_mode) GSAT_REQUIRE(a->src && a->dst && a->Q, GSAT_ERR_ARG, "%s: edge mode needs src, dst, Q", who);
+    else GSAT_REQUIRE(a->M == a->N, GSAT_ERR_ARG, "%s: node mode needs M == N", who);
+    return GSAT_OK;
+}
+
+}  // namespace gsat
+
+using namespace gsat;
+
+extern "C" {
+
+int gsat_attn_fwd(const gsat_attn_args* a, void* stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    int rc = check_args(a, "gsat_attn_fwd");
+    if (rc) return rc;
+    if (a->M == 0) return GSAT_OK;
+    const int64_t M = a->M, N = a->N, G = a->G;
+    const int H = a->H, C1 = a->C1, C2 = a->C2;
+    float* mean1 = a->stats;
+    float* rstd1 = mean1 + (size_t)G * C1;
+    float* mean2 = rstd1 + (size_t)G * C1;
+    float* rstd2 = mean2 + (size_t)G * C2;
+    // ---- layer 1 on nodes -------------------------------------------------------------------
+    if (a->edge_mode) {
+        if ((rc = gemm_rm(stream, false, true, N, C1, H, 1.f, a->emb, H, a->W1, 2 * H, 0.f, a->P, C1))) return rc;        // P = emb W1[:, :H]^T
+        if ((rc = gemm_rm(stream, false, true, N, C1, H, 1.f, a->emb, H, a->W1 + H, 2 * H, 0.f, a->Q, C1))) return rc;    // Q = emb W1[:, H:]^T
+    } else {
+        if ((rc = gemm_rm(stream, false, true, N, C1, H, 1.f, a->emb, H, a->W1, H, 0.f, a->P, C1))) return rc;
+    }
+    const dim3 g1((unsigned)G, (unsigned)ceil_div(C1, 64)), g2((unsigned)G, (unsigned)ceil_div(C2, 64));
+    if (a->edge_mode) {
+        PreAct<true> pre{a->P, a->Q, a->b1, a->src, a->dst, C1};
+        if (G > 0) k_seg_stats<true><<<g1, SB, 0, stream>>>(pre, a->seg_ptr, a->seg_order, mean1, rstd1);
+        k_norm_apply<true, true><<<ew_blocks(M * (C1 / 4)), 256, 0, stream>>>(pre, a->row_seg, mean1, rstd1, a->mask1, a->seed, 1, a->p_drop, a->training, M, a->a1);
+    } else {
+        PreAct<false> pre{a->P, nullptr, a->b1, nullptr, nullptr, C1};
+        if (G > 0) k_seg_stats<false><<<g1, SB, 0, stream>>>(pre, a->seg_ptr, a->seg_order, mean1, rstd1);
+        k_norm_apply<false, true><<<ew_blocks(M * (C1 / 4)), 256, 0, stream>>>(pre, a->row_seg, mean1, rstd1, a->mask1, a->seed, 1, a->p_drop, a->training, M, a->a1);
+    }
+    GSAT_LAUNCH_CHECK();
+    // ---- layer 2 ----------------------------------------------------------------------------
+    if ((rc = gemm_rm(stream, false, true, M, C2, C1, 1.f, a->a1, C1, a->W2, C1, 0.f, a->h2, C2))) return rc;
+    {
+        PreAct<false> pre{a->h2, nullptr, a->b2, nullptr, nullptr, C2};
+        if (G > 0) k_seg_stats<false><<<g2, SB, 0, stream>>>(pre, a->seg_ptr, a->seg_order, mean2, rstd2);
+        GSAT_LAUNCH_CHECK();
+    }
+    // ---- head + sampler ---------------------------------------------------------------------
+    const int q = C2 / 4;
+    const int lpr = q <= 4 ? 4 : q <= 8 ? 8 : q <= 16 ? 16 : q <= 32 ? 32 : 64;
+    const int nb = (int)std::min<int64_t>(ceil_div(M, 256 / lpr), 256 * 32);
+#define HEAD(L) k_head_fwd<L><<<nb, 256, 0, stream>>>(a->h2, a->b2, a->row_seg, mean2, rstd2, a->mask2, a->seed, a->p_drop, a->training, a->W3, a->b3, a->u, M, C2, a->logits, a->att)
+    switch (lpr) { case 4: HEAD(4); break; case 8: HEAD(8); break; case 16: HEAD(16); break; case 32: HEAD(32); break; default: HEAD(64); break; }
+#undef HEAD
+    GSAT_LAUNCH_CHECK();
+    return GSAT_OK;
+}
+
+size_t gsat_attn_bwd_workspace_bytes(const gsat_attn_args* a) {
+    if (!a) return 0;
+    const size_t M = (size_t)a->M, N = (size_t)a->N, G = (size_t)a->G, C1 = a->C1, C2 = a->C2;
+    const size_t cmax = C1 > C2 ? C1 : C2;
+    size_t b = 0;
+    b += align_up(M * 4, 256);                 // dz
+    b += align_up(M * C2 * 4, 256);            // dh2
+    b += align_up(M * C1 * 4, 256);            // da1 -> dh1
+    b += 2 * align_up(G * C1 * 4, 256);        // S1', S2'
+    b += 3 * align_up(G * C2 * 4, 256);        // S1, S2, dw3 partial
+    b += align_up(256 * cmax * 4, 256);        // column-sum scratch
+    if (a->edge_mode) b += 2 * align_up(N * C1 * 4, 256);   // dP, dQ
+    return b + 1024;
+}
+
+int gsat_attn_bwd(const gsat_attn_args* a, const gsat_attn_grads* gr, void* stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    int rc = check_args(a, "gsat_attn_bwd");
+    if (rc) return rc;
+    GSAT_REQUIRE(gr && gr->demb && gr->dW1 && gr->db1 && gr->dW2 && gr->db2 && gr->dW3 && gr->db3, GSAT_ERR_ARG, "gsat_attn_bwd: null gradient output");
+    const int64_t M = a->M, N = a->N, G = a->G;
+    const int H = a->H, C1 = a->C1, C2 = a->C2;
+    const int C0 = a->edge_mode ? 2 * H : H;
+    if (M == 0) {
+        GSAT_CHECK_HIP(hipMemsetAsync(gr->demb, 0, sizeof(float) * N * H, stream));
+        GSAT_CHECK_HIP(hipMemsetAsync(gr->dW1, 0, sizeof(float) * C1 * C0, stream));
+        GSAT_CHECK_HIP(hipMemsetAsync(gr->db1, 0, sizeof(float) * C1, stream));
+        GSAT_CHECK_HIP(hipMemsetAsync(gr->dW2, 0, sizeof(float) * C2 * C1, stream));
+        GSAT_CHECK_HIP(hipMemsetAsync(gr->db2, 0, sizeof(float) * C2, stream));
+        GSAT_CHECK_HIP(hipMemsetAsync(gr->dW3, 0, sizeof(float) * C2, stream));
+        GSAT_CHECK_HIP(hipMemsetAsync(gr->db3, 0, sizeof(float), stream));
+        return GSAT_OK;
+    }
+    GSAT_REQUIRE(gr->dlogits || gr->datt, GSAT_ERR_ARG, "gsat_attn_bwd: need dlogits and/or datt");
+    GSAT_REQUIRE(!gr->datt || a->att, GSAT_ERR_ARG, "gsat_attn_bwd: datt given but att was not saved");
+    if (a->edge_mode) GSAT_REQUIRE(gr->rowptr_src && gr->eid_by_src && gr->rowptr_dst && gr->eid_by_dst, GSAT_ERR_ARG, "gsat_attn_bwd: edge mode needs both CSRs");
+    Arena ar(gr->workspace, gr->workspace_bytes);
+    float* dz = ar.take<float>(M);
+    float* dh2 = ar.take<float>((size_t)M * C2);
+    float* da1 = ar.take<float>((size_t)M * C1);
+    float* S1p = ar.take<float>((size_t)G * C1);
+    float* S2p = ar.take<float>((size_t)G * C1);
+    float* S1 = ar.take<float>((size_t)G * C2);
+    float* S2 = ar.take<float>((size_t)G * C2);
+    float* dw3p = ar.take<float>((size_t)G * C2);
+    float* scratch = ar.take<float>((size_t)256 * std::max(C1, C2));
+    float *dP = nullptr, *dQ = nullptr;
+    if (a->edge_mode) { dP = ar.take<float>((size_t)N * C1); dQ = ar.take<float>((size_t)N * C1); }
+    GSAT_REQUIRE(ar.ok(), GSAT_ERR_WORKSPACE, "gsat_attn_bwd: workspace %zu < %zu", gr->workspace_bytes, ar.off);
+    float* mean1 = a->stats;
+    float* rstd1 = mean1 + (size_t)G * C1;
+    float* mean2 = rstd1 + (size_t)G * C1;
+    float* rstd2 = mean2 + (size_t)G * C2;
+    const float sc = (a->training && a->p_drop > 0.f) ? 1.f / (1.f - a->p_drop) : 1.f;
+
+    k_dz<<<(unsigned)ceil_div(M, 256), 256, 0, stream>>>(gr->dlogits, gr->datt, a->att, M, dz);
+    GSAT_LAUNCH_CHECK();
+    if ((rc = colsum(stream, dz, M, 1, gr->db3, scratch))) return rc;
+    // ---- through the head and the second InstanceNorm ------------------------------------------
+    const dim3 g2((unsigned)G, (unsigned)ceil_div(C2, 64)), g1((unsigned)G, (unsigned)ceil_div(C1, 64));
+    k_head_bwd_stats<<<g2, SB, 0, stream>>>(a->h2, a->b2, a->seg_ptr, a->seg_order, mean2, rstd2, a->mask2, a->seed, a->p_drop,
+                                            a->training, a->W3, dz, C2, S1, S2, dw3p);
+    GSAT_LAUNCH_CHECK();
+    if ((rc = colsum(stream, dw3p, G, C2, gr->dW3, scratch))) return rc;
+    k_dh2<<<ew_blocks(M * (C2 / 4)), 256, 0, stream>>>(a->h2, a->b2, a->row_seg, mean2, rstd2, a->mask2, a->seed, a->p_drop, a->training,
+                                                       a->W3, dz, S1, S2, M, C2, dh2);
+    GSAT_LAUNCH_CHECK();
+    // b1 and b2 sit in front of an InstanceNorm, which removes any per-channel constant of its segment: their
+    // gradients are exactly zero (the reference's autograd returns ~1e-7 rounding noise of a cancelling sum).
+    GSAT_CHECK_HIP(hipMemsetAsync(gr->db2, 0, sizeof(float) * C2, stream));
+    GSAT_CHECK_HIP(hipMemsetAsync(gr->db1, 0, sizeof(float) * C1, stream));
+    // dW2[C2,C1] = dh2^T a1 ; da1[M,C1] = dh2 W2
+    if ((rc = gemm_rm(stream, true, false, C2, C1, M, 1.f, dh2, C2, a->a1, C1, 0.f, gr->dW2, C1))) return rc;
+    if ((rc = gemm_rm(stream, false, false, M, C1, C2, 1.f, dh2, C2, a->W2, C1, 0.f, da1, C1))) return rc;
+    // ---- through ReLU/dropout and the first InstanceNorm ---------------------------------------
+    k_l1_bwd_stats<<<g1, SB, 0, stream>>>(da1, a->a1, a->seg_ptr, a->seg_order, sc, C1, S1p, S2p);
+    GSAT_LAUNCH_CHECK();
+    if (a->edge_mode) {
+        PreAct<true> pre{a->P, a->Q, a->b1, a->src, a->dst, C1};
+        k_dh1<true><<<ew_blocks(M * (C1 / 4)), 256, 0, stream>>>(pre, a->row_seg, mean1, rstd1, a->a1, sc, S1p, S2p, M, da1);
+        GSAT_LAUNCH_CHECK();
+        const int nbn = (int)std::min<int64_t>(ceil_div(N, 4), 256 * 16);
+        k_rows_by_eid<<<nbn, 256, 0, stream>>>(da1, gr->rowptr_src, gr->eid_by_src, (int)N, C1, dP);
+        k_rows_by_eid<<<nbn, 256, 0, stream>>>(da1, gr->rowptr_dst, gr->eid_by_dst, (int)N, C1, dQ);
+        GSAT_LAUNCH_CHECK();
+        // demb = dP W1a + dQ W1b ; dW1[:, :H] = dP^T emb ; dW1[:, H:] = dQ^T emb
+        if ((rc = gemm_rm(stream, false, false, N, H, C1, 1.f, dP, C1, a->W1, 2 * H, 0.f, gr->demb, H))) return rc;
+        if ((rc = gemm_rm(stream, false, false, N, H, C1, 1.f, dQ, C1, a->W1 + H, 2 * H, 1.f, gr->demb, H))) return rc;
+        if ((rc = gemm_rm(stream, true, false, C1, H, N, 1.f, dP, C1, a->emb, H, 0.f, gr->dW1, 2 * H))) return rc;
+        if ((rc = gemm_rm(stream, true, false, C1, H, N, 1.f, dQ, C1, a->emb, H, 0.f, gr->dW1 + H, 2 * H))) return rc;
+    } else {
+        PreAct<false> pre{a->P, nullptr, a->b1, nullptr, nullptr, C1};
+        k_dh1<false><<<ew_blocks(M * (C1 / 4)), 256, 0, stream>>>(pre, a->row_seg, mean1, rstd1, a->a1, sc, S1p, S2p, M, da1);
+        GSAT_LAUNCH_CHECK();
+        if ((rc = gemm_rm(stream, false, false, N, H, C1, 1.f, da1, C1, a->W1, H, 0.f, gr->demb, H))) return rc;
+        if ((rc = gemm_rm(stream, true, false, C1, H, N, 1.f, da1, C1, a->emb, H, 0.f, gr->dW1, H))) return rc;
+    }
+    return GSAT_OK;
+}
+
+int gsat_instance_norm_fwd(const float* x, const int32_t* seg_ptr, const int32_t* seg_order, const int32_t* row_seg, int64_t M,
+                           int64_t G, int64_t C, float* y, float* stats, void* stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    GSAT_REQUIRE(M >= 0 && G >= 0 && C > 0 && C % 4 == 0 && M < (1ll << 31), GSAT_ERR_UNSUPPORTED, "gsat_instance_norm_fwd: C must be a positive multiple of 4");
+    if (M == 0 || G == 0) return GSAT_OK;
+    GSAT_REQUIRE(x && seg_ptr && row_seg && y && stats, GSAT_ERR_ARG, "gsat_instance_norm_fwd: null pointer");
+    float* mean = stats;
+    float* rstd = stats + (size_t)G * C;
+    PreAct<false> pre{x, nullptr, nullptr, nullptr, nullptr, (int)C};
+    k_seg_stats<false><<<dim3((unsigned)G, (unsigned)ceil_div(C, 64)), SB, 0, stream>>>(pre, seg_ptr, seg_order, mean, rstd);
+    k_norm_apply<false, false><<<ew_blocks(M * (C / 4)), 256, 0, stream>>>(pre, row_seg, mean, rstd, nullptr, 0, 0, 0.f, 0, M, y);
+    GSAT_LAUNCH_CHECK();
+    return GSAT_OK;
+}
+
+int gsat_instance_norm_bwd(const float* y, const float* dy, const float* stats, const int32_t* seg_ptr, const int32_t* seg_order,
+                           const int32_t* row_seg, int64_t M, int64_t G, int64_t C, float* dx, float* workspace, void* stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    GSAT_REQUIRE(M >= 0 && G >= 0 && C > 0 && C % 4 == 0 && M < (1ll << 31), GSAT_ERR_UNSUPPORTED, "gsat_instance_norm_bwd: C must be a positive multiple of 4");
+    if (M == 0 || G == 0) return GSAT_OK;
+    GSAT_REQUIRE(y && dy && stats && seg_ptr && row_seg && dx && workspace, GSAT_ERR_ARG, "gsat_instance_norm_bwd: null pointer");
+    float* S1 = workspace;
+    float* S2 = workspace + (size_t)G * C;
+    k_in_bwd_stats<<<dim3((unsigned)G, (unsigned)ceil_div(C, 64)), SB, 0, stream>>>(y, dy, seg_ptr, seg_order, (int)C, S1, S2);
+    k_in_bwd_apply<<<ew_blocks(M * (C / 4)), 256, 0, stream>>>(y, dy, row_seg, stats + (size_t)G * C, S1, S2, M, (int)C, dx);
+    GSAT_LAUNCH_CHECK();
+    return GSAT_OK;
+}
+
+int gsat_philox_keep_mask(uint64_t seed, int32_t layer, int64_t M, int64_t C, float p_drop, float* keep, void* stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    GSAT_REQUIRE(M >= 0 && C > 0 && C % 4 == 0 && M < (1ll << 31), GSAT_ERR_UNSUPPORTED, "gsat_philox_keep_mask: C must be a positive multiple of 4");
+    if (M == 0) return GSAT_OK;
+    GSAT_REQUIRE(keep, GSAT_ERR_ARG, "gsat_philox_keep_mask: null pointer");
+    k_philox_mask<<<ew_blocks(M * (C / 4)), 256, 0, stream>>>(seed, layer, M, (int)C, p_drop, keep);
+    GSAT_LAUNCH_CHECK();
+    return GSAT_OK;
+}
+
+}  // extern "C"

@@ -51,6 +51,11 @@ class BatchIndex:
         self.eid_by_src = _i32(E, dev)
         call("gsat_build_csr", ptr(src), ptr(dst), E, N, ptr(self.rowptr_src), ptr(self.dst_by_src),
              ptr(self.eid_by_src), ptr(self._err), ptr(ws), ws_bytes, stream())
+        # int32 copies of the two edge_index rows (original edge order) for the per-edge kernels
+        self.src32 = _i32(E, dev)
+        self.dst32 = _i32(E, dev)
+        call("gsat_narrow_i64", ptr(src.contiguous()), E, ptr(self.src32), stream())
+        call("gsat_narrow_i64", ptr(dst.contiguous()), E, ptr(self.dst32), stream())
         self._checked = False
         self._rev = None
         self._undirected = None
@@ -126,6 +131,8 @@ class GraphSegments:
         call("gsat_segment_ptr", ptr(self.batch), n, self.G, ptr(self.node_ptr), ptr(flags), stream())
         self._flags = flags
         self._edge = None
+        self.node_seg32 = _i32(n, dev)            # graph id of every node, int32
+        call("gsat_narrow_i64", ptr(self.batch), n, ptr(self.node_seg32), stream())
 
     def check(self):
         if int(self._flags.item()) != 0:
@@ -133,7 +140,7 @@ class GraphSegments:
 
     @property
     def edge_segments(self):
-        """(edge_ptr int32[G+1], edge_order int32[E], edge_graph int64[E]): edges grouped by the graph
+        """(edge_ptr int32[G+1], edge_order int32[E], edge_graph int64[E], edge_graph int32[E]): edges grouped by the graph
         of their SOURCE node -- ``batch[col]`` with ``col = edge_index[0]`` (example/gsat.py:133-136)."""
         if self._edge is None:
             ix = self.index
@@ -146,7 +153,9 @@ class GraphSegments:
             order = _i32(E, dev)
             err = torch.zeros(1, dtype=torch.int32, device=dev)
             call("gsat_build_csr", ptr(eg), None, E, self.G, ptr(eptr), None, ptr(order), ptr(err), ptr(ws), ws_bytes, stream())
-            self._edge = (eptr, order, eg)
+            eg32 = _i32(E, dev)
+            call("gsat_narrow_i64", ptr(eg), E, ptr(eg32), stream())
+            self._edge = (eptr, order, eg, eg32)
         return self._edge
 
 

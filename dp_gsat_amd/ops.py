@@ -167,3 +167,227 @@ def pna_aggregate(x, index, att, edge_emb, aggregators, scalers, avg_deg):
     a = [AGGREGATOR_CODES[k] for k in aggregators]
     s = [SCALER_CODES[k] for k in scalers]
     return PnaAggregate.apply(x, att, edge_emb, index, a, s, avg_deg["lin"], avg_deg["log"])
+
+
+# ------------------------------------------------------------------------------------------------
+# attention extractor MLP (+ fused concrete sampler)
+# ------------------------------------------------------------------------------------------------
+def _attn_args(emb, params, index, segments, edge_mode, training, p, seed, mask1, mask2, u, bufs):
+    from ._lib import AttnArgs
+    W1, b1, W2, b2, W3, b3 = params
+    N, H = emb.shape
+    C1, C2 = W1.shape[0], W2.shape[0]
+    a = AttnArgs()
+    if edge_mode:
+        eptr, order, _, eg32 = segments.edge_segments
+        a.M, a.seg_ptr, a.seg_order, a.row_seg = index.E, ptr(eptr), ptr(order), ptr(eg32)
+        a.src, a.dst = ptr(index.src32), ptr(index.dst32)
+    else:
+        a.M, a.seg_ptr, a.seg_order, a.row_seg = N, ptr(segments.node_ptr), None, ptr(segments.node_seg32)
+        a.src, a.dst = None, None
+    a.N, a.G, a.H, a.C1, a.C2 = N, segments.G, H, C1, C2
+    a.edge_mode, a.training, a.p_drop, a.seed = int(edge_mode), int(training), float(p), int(seed) & ((1 << 64) - 1)
+    a.W1, a.b1, a.W2, a.b2, a.W3, a.b3 = ptr(W1), ptr(b1), ptr(W2), ptr(b2), ptr(W3), ptr(b3)
+    a.emb, a.mask1, a.mask2, a.u = ptr(emb), ptr(mask1), ptr(mask2), ptr(u)
+    P, Q, a1, h2, stats, logits, att = bufs
+    a.P, a.Q, a.a1, a.h2, a.stats, a.logits, a.att = ptr(P), ptr(Q), ptr(a1), ptr(h2), ptr(stats), ptr(logits), ptr(att)
+    return a
+
+
+class ExtractorAttention(torch.autograd.Function):
+    """(logits, att) = sampler(MLP([emb[src] || emb[dst]] | emb, per-graph InstanceNorm)).
+
+    replaces: ExtractorMLP.forward + MLP/BatchSequential/InstanceNorm + GSAT.sampling
+    (example/gsat.py:94-103,131-139; src/utils/get_model.py:47-68; src/run_gsat.py:877-927)."""
+
+    @staticmethod
+    def forward(ctx, emb, W1, b1, W2, b2, W3, b3, index, segments, edge_mode, training, p, seed, mask1, mask2, u):
+        import ctypes
+        emb = _f32c(emb)
+        params = tuple(_f32c(t) for t in (W1, b1, W2, b2, W3, b3))
+        mask1, mask2 = _f32c(mask1), _f32c(mask2)
+        u = None if u is None else _f32c(u).view(-1)
+        N, H = emb.shape
+        C1, C2 = params[0].shape[0], params[2].shape[0]
+        C0 = 2 * H if edge_mode else H
+        if params[0].shape[1] != C0 or params[2].shape[1] != C1 or tuple(params[4].shape) != (1, C2):
+            raise ValueError("extractor weight shapes do not match the embedding width")
+        if N != index.N:
+            raise ValueError(f"emb has {N} rows but the index was built for {index.N} nodes")
+        M = index.E if edge_mode else N
+        for m_, c_ in ((mask1, C1), (mask2, C2)):
+            if m_ is not None and tuple(m_.shape) != (M, c_):
+                raise ValueError("dropout keep-mask has the wrong shape")
+        if u is not None and u.numel() != M:
+            raise ValueError("noise tensor has the wrong number of entries")
+        dev, f32 = emb.device, torch.float32
+        G = segments.G
+        P = torch.empty(N, C1, dtype=f32, device=dev)
+        Q = torch.empty(N, C1, dtype=f32, device=dev) if edge_mode else None
+        a1 = torch.empty(M, C1, dtype=f32, device=dev)
+        h2 = torch.empty(M, C2, dtype=f32, device=dev)
+        stats = torch.empty(max(G, 1) * (2 * C1 + 2 * C2), dtype=f32, device=dev)
+        logits = torch.empty(M, 1, dtype=f32, device=dev)
+        att = torch.empty(M, 1, dtype=f32, device=dev)
+        bufs = (P, Q, a1, h2, stats, logits, att)
+        args = _attn_args(emb, params, index, segments, edge_mode, training, p, seed, mask1, mask2, u, bufs)
+        call("gsat_attn_fwd", ctypes.byref(args), stream())
+        ctx.save_for_backward(emb, *params, P, Q if Q is not None else emb.new_empty(0), a1, h2, stats, att,
+                              mask1 if mask1 is not None else emb.new_empty(0),
+                              mask2 if mask2 is not None else emb.new_empty(0),
+                              u if u is not None else emb.new_empty(0))
+        ctx.meta = (index, segments, bool(edge_mode), bool(training), float(p), int(seed),
+                    mask1 is not None, mask2 is not None, u is not None)
+        return logits, att
+
+    @staticmethod
+    def backward(ctx, dlogits, datt):
+        import ctypes
+        from ._lib import AttnGrads, load
+        (emb, W1, b1, W2, b2, W3, b3, P, Q, a1, h2, stats, att, mask1, mask2, u) = ctx.saved_tensors
+        index, segments, edge_mode, training, p, seed, has_m1, has_m2, has_u = ctx.meta
+        params = (W1, b1, W2, b2, W3, b3)
+        logits_dummy = att  # not read by the backward
+        bufs = (P, Q if edge_mode else None, a1, h2, stats, logits_dummy, att)
+        args = _attn_args(emb, params, index, segments, edge_mode, training, p, seed, mask1 if has_m1 else None,
+                          mask2 if has_m2 else None, u if has_u else None, bufs)
+        g = AttnGrads()
+        dlogits = None if dlogits is None else _f32c(dlogits)
+        datt = None if datt is None else _f32c(datt)
+        g.dlogits, g.datt = ptr(dlogits), ptr(datt)
+        if edge_mode:
+            g.rowptr_src, g.eid_by_src = ptr(index.rowptr_src), ptr(index.eid_by_src)
+            g.rowptr_dst, g.eid_by_dst = ptr(index.rowptr_dst), ptr(index.eid_by_dst)
+        demb = torch.empty_like(emb)
+        grads = [torch.empty_like(t) for t in params]
+        g.demb = ptr(demb)
+        g.dW1, g.db1, g.dW2, g.db2, g.dW3, g.db3 = (ptr(t) for t in grads)
+        ws_bytes = int(load().gsat_attn_bwd_workspace_bytes(ctypes.byref(args)))
+        ws = torch.empty(ws_bytes, dtype=torch.uint8, device=emb.device)
+        g.workspace, g.workspace_bytes = ptr(ws), ws_bytes
+        call("gsat_attn_bwd", ctypes.byref(args), ctypes.byref(g), stream())
+        return (demb, *grads, None, None, None, None, None, None, None, None, None)
+
+
+def new_seed() -> int:
+    """63-bit Philox seed drawn from torch's CPU generator (follows torch.manual_seed, no device sync)."""
+    return int(torch.empty((), dtype=torch.int64).random_().item())
+
+
+class Sample(torch.autograd.Function):
+    """sigmoid((logits + noise)/temp): concrete (mode 1) / Gumbel (mode 2) / none (mode 0)."""
+
+    @staticmethod
+    def forward(ctx, logits, noise, mode: int, temp: float, eps: float):
+        z = _f32c(logits)
+        nz = None if noise is None else _f32c(noise)
+        att = torch.empty_like(z)
+        call("gsat_sample_fwd", ptr(z), ptr(nz), int(mode), float(temp), float(eps), z.numel(), ptr(att), stream())
+        ctx.save_for_backward(att)
+        ctx.temp = float(temp)
+        return att
+
+    @staticmethod
+    def backward(ctx, datt):
+        (att,) = ctx.saved_tensors
+        datt = _f32c(datt)
+        dz = torch.empty_like(att)
+        call("gsat_sample_bwd", ptr(att), ptr(datt), ctx.temp, att.numel(), ptr(dz), stream())
+        return dz, None, None, None, None
+
+
+class Lift(torch.autograd.Function):
+    """edge_att = node_att[src] * node_att[dst]  (example/gsat.py:112-117)."""
+
+    @staticmethod
+    def forward(ctx, node_att, index: BatchIndex):
+        a = _f32c(node_att)
+        if a.numel() != index.N:
+            raise ValueError("node attention must have one entry per node")
+        out = torch.empty(index.E, 1, dtype=torch.float32, device=a.device)
+        call("gsat_lift_fwd", ptr(a), ptr(index.src32), ptr(index.dst32), index.E, ptr(out), stream())
+        ctx.save_for_backward(a)
+        ctx.index = index
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        (a,) = ctx.saved_tensors
+        ix = ctx.index
+        dout = _f32c(dout)
+        da = torch.empty_like(a)
+        call("gsat_lift_bwd", ptr(a), ptr(dout), ptr(ix.rowptr_src), ptr(ix.dst_by_src), ptr(ix.eid_by_src),
+             ptr(ix.rowptr_dst), ptr(ix.src_by_dst), ptr(ix.eid_by_dst), ix.N, ptr(da), stream())
+        return da, None
+
+
+class Symmetrise(torch.autograd.Function):
+    """(att + att[rev]) / 2  (example/gsat.py:81-83)."""
+
+    @staticmethod
+    def forward(ctx, att, rev):
+        a = _f32c(att)
+        out = torch.empty_like(a)
+        call("gsat_symmetrise", ptr(a), ptr(rev), a.numel(), ptr(out), stream())
+        ctx.save_for_backward(rev)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        (rev,) = ctx.saved_tensors
+        d = _f32c(dout)
+        da = torch.empty_like(d)
+        call("gsat_symmetrise", ptr(d), ptr(rev), d.numel(), ptr(da), stream())
+        return da, None
+
+
+class InfoLoss(torch.autograd.Function):
+    """mean(att*log(att/r+1e-6) + (1-att)*log((1-att)/(1-r+1e-6)+1e-6)); r scalar or detached tensor prior."""
+
+    @staticmethod
+    def forward(ctx, att, r):
+        a = _f32c(att)
+        r_vec = _f32c(r.detach()) if isinstance(r, torch.Tensor) else None
+        r_scalar = 0.0 if r_vec is not None else float(r)
+        if r_vec is not None and r_vec.numel() != a.numel():
+            raise ValueError("tensor prior must have one entry per attention value")
+        out = torch.empty((), dtype=torch.float32, device=a.device)
+        partial = torch.empty(1024, dtype=torch.float32, device=a.device)
+        call("gsat_info_loss_fwd", ptr(a), ptr(r_vec), r_scalar, a.numel(), ptr(partial), ptr(out), stream())
+        ctx.save_for_backward(a, r_vec if r_vec is not None else a.new_empty(0))
+        ctx.r_scalar, ctx.has_vec = r_scalar, r_vec is not None
+        return out
+
+    @staticmethod
+    def backward(ctx, gout):
+        a, r_vec = ctx.saved_tensors
+        gout = _f32c(gout)
+        da = torch.empty_like(a)
+        call("gsat_info_loss_bwd", ptr(a), ptr(r_vec if ctx.has_vec else None), ctx.r_scalar, ptr(gout), a.numel(), ptr(da), stream())
+        return da, None
+
+
+class InstanceNormFn(torch.autograd.Function):
+    """per-graph InstanceNorm (eps 1e-5, no affine, batch statistics always) -- src/utils/get_model.py:50-51."""
+
+    @staticmethod
+    def forward(ctx, x, seg_ptr, seg_order, row_seg, G):
+        x = _f32c(x)
+        M, C = x.shape
+        y = torch.empty_like(x)
+        stats = torch.empty(max(G, 1) * 2 * C, dtype=torch.float32, device=x.device)
+        call("gsat_instance_norm_fwd", ptr(x), ptr(seg_ptr), ptr(seg_order), ptr(row_seg), M, G, C, ptr(y), ptr(stats), stream())
+        ctx.save_for_backward(y, stats, seg_ptr, row_seg, seg_order if seg_order is not None else seg_ptr.new_empty(0))
+        ctx.G, ctx.has_order = G, seg_order is not None
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        y, stats, seg_ptr, row_seg, seg_order = ctx.saved_tensors
+        dy = _f32c(dy)
+        M, C = y.shape
+        dx = torch.empty_like(y)
+        ws = torch.empty(max(ctx.G, 1) * 2 * C, dtype=torch.float32, device=y.device)
+        call("gsat_instance_norm_bwd", ptr(y), ptr(dy), ptr(stats), ptr(seg_ptr), ptr(seg_order if ctx.has_order else None),
+             ptr(row_seg), M, ctx.G, C, ptr(dx), ptr(ws), stream())
+        return dx, None, None, None, None

@@ -159,6 +159,122 @@ int gsat_pna_bwd(const float* x, const float* att, const float* edge_emb, const 
                  float avg_deg_lin, float avg_deg_log, float* dx_self, float* dmsg, float* datt,
                  float* dedge_emb, void* stream);
 
+/* =============================== attention extractor MLP ===================================== */
+
+/*
+ * ExtractorMLP + concrete sampler:
+ *   edge mode:  z_e = MLP([emb[src_e] || emb[dst_e]], segment = batch[src_e])   (M = E rows)
+ *   node mode:  z_n = MLP(emb[n], segment = batch[n])                            (M = N rows)
+ *   MLP = Linear(C0,C1) -> InstanceNorm(per graph) -> ReLU -> Dropout(p)
+ *      -> Linear(C1,C2) -> InstanceNorm -> ReLU -> Dropout(p) -> Linear(C2,1)
+ *   InstanceNorm: per-graph, per-channel mean, biased variance of the centred values, eps 1e-5,
+ *   no affine, batch statistics in train and eval.
+ *   att = sigmoid(z + log u - log(1-u)) when `training` and `u` given, else sigmoid(z).
+ * replaces: ExtractorMLP.forward (example/gsat.py:131-139; src/run_gsat.py:909-927), MLP /
+ *   BatchSequential / InstanceNorm / ReLU / Dropout (src/utils/get_model.py:47-68) and
+ *   GSAT.sampling / concrete_sample (example/gsat.py:94-103; src/run_gsat.py:877-885).
+ * In edge mode layer 1 is evaluated on NODES (P = emb W1[:, :H]^T, Q = emb W1[:, H:]^T, then
+ * h1_e = P[src_e] + Q[dst_e] + b1), so the [E, 2H] concat and the E-row first GEMM never exist.
+ * Dropout keep-masks: `mask1/mask2` (float 0/1) if given, else Philox4x32-10 of (seed, layer, row, col).
+ */
+typedef struct gsat_attn_args {
+    int64_t M, N, G;
+    int32_t H, C1, C2;
+    int32_t edge_mode;
+    int32_t training;
+    float p_drop;
+    uint64_t seed;
+    const int32_t* src;        /* [E] int32 edge_index[0]   (edge mode) */
+    const int32_t* dst;        /* [E] int32 edge_index[1]   (edge mode) */
+    const int32_t* seg_ptr;    /* [G+1] MLP rows grouped by graph */
+    const int32_t* seg_order;  /* [M] row ids in grouped order, NULL = identity */
+    const int32_t* row_seg;    /* [M] graph id of every row */
+    const float *W1, *b1, *W2, *b2, *W3, *b3;   /* nn.Linear layout [out, in] */
+    const float* emb;          /* [N,H] */
+    const float* mask1;        /* nullable [M,C1] */
+    const float* mask2;        /* nullable [M,C2] */
+    const float* u;            /* nullable [M] */
+    float* P;                  /* [N,C1] saved: edge P ; node h1 (no bias) */
+    float* Q;                  /* [N,C1] saved: edge Q ; node: NULL */
+    float* a1;                 /* [M,C1] saved: dropout(relu(norm(h1))) */
+    float* h2;                 /* [M,C2] saved: a1 W2^T (no bias) */
+    float* stats;              /* [G*(2*C1+2*C2)] saved: mean1 | rstd1 | mean2 | rstd2 */
+    float* logits;             /* [M] out */
+    float* att;                /* [M] out, nullable */
+} gsat_attn_args;
+
+typedef struct gsat_attn_grads {
+    const float* dlogits;      /* nullable [M] gradient w.r.t. logits */
+    const float* datt;         /* nullable [M] gradient w.r.t. att (needs args->att) */
+    const int32_t* rowptr_src; /* edge mode: by-source CSR + edge ids */
+    const int32_t* eid_by_src;
+    const int32_t* rowptr_dst; /* edge mode: by-destination CSR + edge ids */
+    const int32_t* eid_by_dst;
+    float *demb, *dW1, *db1, *dW2, *db2, *dW3, *db3;
+    void* workspace;
+    size_t workspace_bytes;
+} gsat_attn_grads;
+
+size_t gsat_attn_bwd_workspace_bytes(const gsat_attn_args* args);
+int gsat_attn_fwd(const gsat_attn_args* args, void* stream);
+int gsat_attn_bwd(const gsat_attn_args* args, const gsat_attn_grads* grads, void* stream);
+
+/* Standalone per-graph InstanceNorm (src/utils/get_model.py:50-51,64) for BatchSequential users.
+ * y = (x - mean_g) * rstd_g ; stats [G*2*C] = mean | rstd (saved for backward). */
+int gsat_instance_norm_fwd(const float* x, const int32_t* seg_ptr, const int32_t* seg_order,
+                           const int32_t* row_seg, int64_t M, int64_t G, int64_t C, float* y,
+                           float* stats, void* stream);
+int gsat_instance_norm_bwd(const float* y, const float* dy, const float* stats, const int32_t* seg_ptr,
+                           const int32_t* seg_order, const int32_t* row_seg, int64_t M, int64_t G,
+                           int64_t C, float* dx, float* workspace /* [G*2*C] */, void* stream);
+
+/* keep[m,c] in {0,1}: the Philox dropout mask gsat_attn_* uses for (seed, layer, row m, column c). */
+int gsat_philox_keep_mask(uint64_t seed, int32_t layer, int64_t M, int64_t C, float p_drop, float* keep,
+                          void* stream);
+
+/* ============================ samplers, lift, symmetrise, info loss ========================== */
+
+/*
+ * att = sigmoid((logits + noise_term) / temp);  mode 0: no noise (eval);
+ * mode 1 (concrete): noise_term = log(u) - log(1-u), u = noise[m]   (example/gsat.py:94-103)
+ * mode 2 (gumbel):   noise_term = -log(-log(U + eps) + eps)          (src/run_gsat.py:182-187)
+ * backward: dlogits = datt * att * (1 - att) / temp.
+ */
+int gsat_sample_fwd(const float* logits, const float* noise, int mode, float temp, float eps, int64_t M,
+                    float* att, void* stream);
+int gsat_sample_bwd(const float* att, const float* datt, float temp, int64_t M, float* dlogits, void* stream);
+
+/*
+ * edge_att[e] = node_att[src_e] * node_att[dst_e]
+ * replaces: lift_node_att_to_edge_att (example/gsat.py:112-117, src/run_gsat.py:870-875).
+ * backward walks both CSRs (no atomics): dnode[n] = sum_out d_e a[dst_e] + sum_in d_e a[src_e].
+ */
+int gsat_lift_fwd(const float* node_att, const int32_t* src, const int32_t* dst, int64_t num_edges,
+                  float* edge_att, void* stream);
+int gsat_lift_bwd(const float* node_att, const float* dedge_att, const int32_t* rowptr_src,
+                  const int32_t* dst_by_src, const int32_t* eid_by_src, const int32_t* rowptr_dst,
+                  const int32_t* src_by_dst, const int32_t* eid_by_dst, int64_t num_nodes,
+                  float* dnode_att, void* stream);
+
+/*
+ * out[k] = (att[k] + att[rev[k]]) / 2 ; rev from gsat_reverse_edge_perm (an involution, so the same
+ * call maps d(out) to d(att)).  replaces: example/gsat.py:81-83, src/run_gsat.py:233-235,243-245.
+ */
+int gsat_symmetrise(const float* att, const int32_t* rev, int64_t num_edges, float* out, void* stream);
+
+/*
+ * out[0] = mean_m [ a log(a/r + 1e-6) + (1-a) log((1-a)/(1-r+1e-6) + 1e-6) ], r = r_vec[m] if r_vec
+ * else r_scalar.  replaces: example/gsat.py:31; src/run_gsat.py:127,132 (tensor prior).
+ * partial: scratch float[1024].  backward: datt[m] = gout[0]/M * d term / d a (r is detached).
+ */
+int gsat_info_loss_fwd(const float* att, const float* r_vec, float r_scalar, int64_t M, float* partial,
+                       float* out, void* stream);
+int gsat_info_loss_bwd(const float* att, const float* r_vec, float r_scalar, const float* gout, int64_t M,
+                       float* datt, void* stream);
+
+/* out[i] = (int32) in[i] */
+int gsat_narrow_i64(const int64_t* in, int64_t n, int32_t* out, void* stream);
+
 /* ================================ global pools / segment ops ================================ */
 
 /*

@@ -86,7 +86,7 @@ def test_csr_and_rev_bit_exact(dev):
             assert ix.rev is None
         seg = ix.graphs(batch.to(dev))
         assert np.array_equal(seg.node_ptr.cpu().numpy().astype(np.int64), obk.graph_ptr(batch))
-        eptr, order, eg = seg.edge_segments
+        eptr, order, eg, _ = seg.edge_segments
         rp, perm = obk.csr_by(batch[ei[0]], seg.G)
         assert np.array_equal(eptr.cpu().numpy().astype(np.int64), rp)
         assert np.array_equal(order.cpu().numpy().astype(np.int64), perm)
