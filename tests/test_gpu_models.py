@@ -1,0 +1,168 @@
+"""-m gpu: whole backbones and the GSAT step (example/trainer.py:28-36 row) vs the oracle and the committed goldens."""
+import os
+from types import SimpleNamespace as NS
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import modules as om
+from tests.test_oracle_golden import build_oracle, load_case
+from tests.util import close
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _mk_pair(G, backbone, cfg, x_dim, e_dim, H, learn_edge_att, dev, num_class=2):
+    oclf = (om.GIN if backbone == "GIN" else om.PNA)(x_dim, e_dim, num_class, False, cfg)
+    oext = om.ExtractorMLP(H, learn_edge_att)
+    clf = G.get_model(x_dim, e_dim, num_class, False, cfg, dev)
+    clf.load_state_dict(oclf.state_dict())
+    ext = G.ExtractorMLP(H, learn_edge_att).to(dev)
+    ext.load_state_dict(oext.state_dict())
+    return oclf, oext, clf, ext
+
+
+def _step(G, data, oclf, oext, clf, ext, learn_edge_att, H, dev, training=True, num_class=2, epoch=12):
+    M = data.edge_index.shape[1] if learn_edge_att else data.x.shape[0]
+    C1 = 4 * H if learn_edge_att else 2 * H
+    g = torch.Generator().manual_seed(11)
+    u = torch.rand(M, 1, generator=g).clamp_(1e-10, 1 - 1e-10)
+    masks = [(torch.rand(M, C1, generator=g) > 0.5).float(), (torch.rand(M, H, generator=g) > 0.5).float()]
+    ogsat = om.GSAT(oclf, oext, om.Criterion(num_class, False), learn_edge_att=learn_edge_att).train(training)
+    o_att, o_loss, o_ld, o_logits, aux = ogsat.forward_pass(data, epoch, training, u=u, masks=masks)
+    gsat = G.GSAT(clf, ext, G.Criterion(num_class, False), None, learn_edge_att=learn_edge_att).train(training)
+    att, loss, ld, logits = gsat.forward_pass(data.to(dev), epoch, training, noise=u.to(dev), dropout_masks=[m.to(dev) for m in masks])
+    close(att, o_att, what="edge_att")
+    close(logits, o_logits, what="clf_logits")
+    for k in ("loss", "pred", "info"):
+        assert abs(ld[k] - o_ld[k]) <= 1e-4 * max(1.0, abs(o_ld[k])), (k, ld[k], o_ld[k])
+    if training:
+        o_loss.backward()
+        loss.backward()
+        for (k, p), (_, q) in zip(list(clf.named_parameters()) + list(ext.named_parameters()),
+                                  list(oclf.named_parameters()) + list(oext.named_parameters())):
+            if q.grad is None:
+                assert p.grad is None or float(p.grad.abs().max()) == 0.0, k
+                continue
+            close(p.grad, q.grad, 2e-4, what="grad " + k)
+
+
+@pytest.mark.parametrize("training", [True, False])
+def test_gsat_gin_edge_attention_c2(dev, training):
+    """C2: ba_2motifs + GIN, hidden 64, edge attention, symmetrised."""
+    import dp_gsat_amd as G
+    from dp_gsat_amd import synth
+    data = synth.ba2motifs_batch(num_graphs=24, seed=3)
+    H = 64
+    cfg = dict(model_name="GIN", n_layers=2, hidden_size=H, dropout_p=0.0)
+    pair = _mk_pair(G, "GIN", cfg, 10, 0, H, True, dev)
+    _step(G, data, *pair, True, H, dev, training)
+
+
+def test_gsat_gin_node_attention_c1_mutag(dev):
+    """C1: real MUTAG topology (fixture) + GIN hidden 64, node attention (lift)."""
+    import dp_gsat_amd as G
+    from dp_gsat_amd import synth
+    data = synth.mutag_batch(os.path.join(ROOT, "tests", "golden", "mutag128.npz"), num_graphs=32)
+    H = 64
+    cfg = dict(model_name="GIN", n_layers=2, hidden_size=H, dropout_p=0.0)
+    pair = _mk_pair(G, "GIN", cfg, 14, 0, H, False, dev)
+    _step(G, data, *pair, False, H, dev, True)
+
+
+def test_gsat_pna_node_attention_c3(dev):
+    """C3: molhiv-shaped + PNA (mean,min,max,std; identity), atom encoder, node attention."""
+    import dp_gsat_amd as G
+    from dp_gsat_amd import synth
+    data = synth.molhiv_batch(num_graphs=24, seed=5)
+    H = 32
+    cfg = dict(model_name="PNA", n_layers=3, hidden_size=H, dropout_p=0.0, use_edge_attr=False, atom_encoder=True,
+               aggregators=["mean", "min", "max", "std"], scalers=False, deg=synth.in_degree_histogram(data))
+    pair = _mk_pair(G, "PNA", cfg, 9, 0, H, False, dev)
+    _step(G, data, *pair, False, H, dev, True)
+
+
+def test_gsat_gine_directed_c4(dev):
+    """C4: spmotif-shaped, single-direction edges (no symmetrisation), edge_attr = ones -> GINEConv, 3 classes."""
+    import dp_gsat_amd as G
+    from dp_gsat_amd import synth
+    data = synth.spmotif_batch(num_graphs=16, seed=7)
+    H = 32
+    cfg = dict(model_name="GIN", n_layers=2, hidden_size=H, dropout_p=0.0)
+    pair = _mk_pair(G, "GIN", cfg, 4, 1, H, True, dev, num_class=3)
+    assert type(pair[2].convs[0]).__name__ == "GINEConv"
+    _step(G, data, *pair, True, H, dev, True, num_class=3)
+
+
+@pytest.mark.parametrize("name,backbone,edge", [("gin_edge", "GIN", True), ("pna_node", "PNA", False)])
+def test_against_committed_golden(dev, name, backbone, edge):
+    """train_one_batch row of SURVEY 8c: emb, att_log_logits, att, edge_att, clf_logits, loss dict, parameter grads."""
+    import dp_gsat_amd as G
+    c = load_case(name)
+    cfg, oclf, oext = build_oracle(c, backbone, edge)
+    H = 16
+    clf = G.get_model(5, 0, 2, False, cfg, dev)
+    clf.load_state_dict(oclf.state_dict())
+    ext = G.ExtractorMLP(H, edge).to(dev)
+    ext.load_state_dict(oext.state_dict())
+    gsat = G.GSAT(clf, ext, G.Criterion(2, False), None, learn_edge_att=edge).train()
+    data = NS(x=c["x"].to(dev), edge_index=c["edge_index"].to(dev), batch=c["batch"].to(dev), edge_attr=None, y=c["y"].to(dev))
+    emb = clf.get_emb(data.x, data.edge_index, batch=data.batch, edge_attr=None)
+    close(emb, c["emb"], what="emb")
+    z, att = ext.attend(emb, data.edge_index, data.batch, noise=c["u"].to(dev), dropout_masks=[c["mask1"].to(dev), c["mask2"].to(dev)])
+    close(z, c["att_log_logits"], what="att_log_logits")
+    close(att, c["att"], what="att")
+    edge_att, loss, ld, logits = gsat.forward_pass(data, 12, True, noise=c["u"].to(dev),
+                                                   dropout_masks=[c["mask1"].to(dev), c["mask2"].to(dev)])
+    close(edge_att, c["edge_att"], what="edge_att")
+    close(logits, c["clf_logits"], what="clf_logits")
+    assert abs(ld["loss"] - c["loss"].item()) < 1e-4 and abs(ld["info"] - c["info"].item()) < 1e-4
+    loss.backward()
+    for k, p in ext.named_parameters():
+        close(p.grad, c["grad.ext." + k], 2e-4, what="grad ext." + k)
+    for k, p in clf.named_parameters():
+        close(p.grad, c["grad.clf." + k], 2e-4, what="grad clf." + k)
+
+
+def test_backbone_dropout_and_unmasked_call_forms(dev):
+    """keyword call without edge_atten (src/pretrain_clf.py:61,69), get_pred_from_emb(emb, batch), dropout active in train."""
+    import dp_gsat_amd as G
+    from dp_gsat_amd import synth
+    data = synth.ba2motifs_batch(num_graphs=6, seed=1).to(dev)
+    cfg = dict(model_name="GIN", n_layers=2, hidden_size=32, dropout_p=0.3)
+    clf = G.get_model(10, 0, 2, False, cfg, dev).eval()
+    a = clf(data.x, edge_index=data.edge_index, edge_attr=None, batch=data.batch)
+    emb = clf.get_emb(data.x, data.edge_index, batch=data.batch, edge_attr=None)
+    b = clf.get_pred_from_emb(emb, data.batch)
+    assert a.shape == (6, 1) and torch.allclose(a, b, atol=1e-5)
+    clf.train()
+    e1 = clf.get_emb(data.x, data.edge_index, batch=data.batch)
+    assert (e1 == 0).float().mean() > 0.25                 # relu + dropout(0.3) zeros
+
+
+def test_deterministic_bitwise(dev):
+    """Run the same step twice: every output and gradient is bit-identical (no float atomics anywhere)."""
+    import dp_gsat_amd as G
+    from dp_gsat_amd import synth
+    data = synth.molhiv_batch(num_graphs=16, seed=2).to(dev)
+    H = 32
+    cfg = dict(model_name="PNA", n_layers=2, hidden_size=H, dropout_p=0.0, use_edge_attr=False, atom_encoder=True,
+               aggregators=["mean", "min", "max", "std"], scalers=False, deg=synth.in_degree_histogram(data))
+    clf = G.get_model(9, 0, 2, False, cfg, dev)
+    ext = G.ExtractorMLP(H, False).to(dev)
+    gsat = G.GSAT(clf, ext, G.Criterion(2, False), None, learn_edge_att=False).train()
+    u = torch.rand(data.num_nodes, 1, device=dev).clamp_(1e-10, 1 - 1e-10)
+    outs = []
+    for _ in range(2):
+        for p in gsat.parameters():
+            p.grad = None
+        G.clear_cache()
+        torch.manual_seed(123)                       # same Philox dropout seed for both runs
+        att, loss, _, logits = gsat.forward_pass(data, 3, True, noise=u)
+        loss.backward()
+        outs.append([att.clone(), logits.clone(), loss.clone()] + [p.grad.clone() for p in gsat.parameters() if p.grad is not None])
+    assert len(outs[0]) == len(outs[1]) > 10
+    for a, b in zip(*outs):
+        assert torch.equal(a, b)
