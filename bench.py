@@ -1,0 +1,380 @@
+#!/usr/bin/env python3
+"""bench.py -- million directed edges/s through the GSAT hot path on MI355X.
+
+  python bench.py --gpus 1 --steps 20 --warmup 5            # default workload: C3 (molhiv-shaped, PNA H=128, batch 2048)
+  python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...
+
+One *step* (scope A) = [per-batch edge bookkeeping -> extractor MLP fwd -> concrete sample ->
+symmetrise | lift -> L masked aggregations fwd] + the backward of all of it (+ the flat RCCL gradient all-reduce
+when N > 1), on one synthetic collated batch resident in HBM.  `value` = directed edges of all ranks / step time.
+The full GSAT training step (both backbone passes, dense node updates, losses, Adam) is timed next to it and
+reported as `full_step`; the CPU oracle timed on the host cores is `cpu_baseline`; `roofline` prices the masked
+aggregation forward kernel against HBM bandwidth.
+"""
+from __future__ import annotations
+
+import argparse
+import ctypes
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0       # MI355X HBM3E spec peak (/opt/skills/guides/MI355X_MICROARCH.md); measured copy ~6.3 TB/s
+
+WORKLOADS = {
+    # name: backbone, conv, attention mode, hidden, layers, graphs per GPU
+    "c1": dict(desc="C1 MUTAG-shaped (real topology fixture) + GIN H=64 L=2, node attention, 128 graphs", backbone="GIN", H=64, L=2, edge_att=False, graphs=128),
+    "c2": dict(desc="C2 ba_2motifs-shaped + GIN H=64 L=2, edge attention (symmetrised), 512 graphs", backbone="GIN", H=64, L=2, edge_att=True, graphs=512),
+    "c3": dict(desc="C3 ogbg-molhiv-shaped + PNA H=128 L=4 (mean,min,max,std; identity), node attention, 2048 graphs", backbone="PNA", H=128, L=4, edge_att=False, graphs=2048),
+    "c4": dict(desc="C4 spmotif-shaped + GIN/GINEConv H=128 L=2, edge attention (directed, no symmetrisation), 1024 graphs/GPU", backbone="GIN", H=128, L=2, edge_att=True, graphs=1024),
+    "c5s": dict(desc="C5 power-law Chung-Lu (scaled 1/64 of the per-GPU share: 19.5k nodes, 195k edges x2, 2 graphs) + GIN H=256 L=2, edge attention", backbone="GIN", H=256, L=2, edge_att=True, graphs=2),
+}
+PNA_AGGR = ["mean", "min", "max", "std"]
+
+
+def make_batch(name, num_graphs, seed):
+    from dp_gsat_amd import synth
+    if name == "c1":
+        return synth.mutag_batch(os.path.join(ROOT, "tests", "golden", "mutag128.npz"), min(num_graphs, 128)), 14, 0
+    if name == "c2":
+        return synth.ba2motifs_batch(num_graphs, seed), 10, 0
+    if name == "c3":
+        return synth.molhiv_batch(num_graphs, seed), 9, 0
+    if name == "c4":
+        return synth.spmotif_batch(num_graphs, seed), 4, 1
+    if name == "c5s":
+        return synth.powerlaw_batch(num_nodes=19_532 * num_graphs // 2, num_edges=195_312 * num_graphs, num_graphs=num_graphs, seed=seed), 16, 0
+    raise ValueError(name)
+
+
+def local_shard(name, graphs_per_gpu, rank, world, seed):
+    """Weak scaling: the global batch has graphs_per_gpu * world graphs; whole graphs go to ranks by the
+    edge-balanced LPT partition (no data-path collective)."""
+    from dp_gsat_amd.dist import edges_per_graph, shard_graphs_lpt, take_graphs
+    batch, x_dim, e_dim = make_batch(name, graphs_per_gpu * world, seed)
+    if world > 1:
+        parts = shard_graphs_lpt(edges_per_graph(batch), world)
+        batch = take_graphs(batch, parts[rank])
+    return batch, x_dim, e_dim
+
+
+# ------------------------------------------------------------------------------------------------
+# scope A: the hot path proper
+# ------------------------------------------------------------------------------------------------
+class HotPath:
+    def __init__(self, wl, data, dev, seed=0):
+        import dp_gsat_amd as G
+        from dp_gsat_amd import synth
+        self.G, self.wl, self.dev, self.data = G, wl, dev, data
+        g = torch.Generator().manual_seed(seed)
+        N, E, H, L = data.num_nodes, data.num_edges, wl["H"], wl["L"]
+        self.N, self.E = N, E
+        self.ext = G.ExtractorMLP(H, wl["edge_att"]).to(dev).train()
+        self.emb = torch.randn(N, H, generator=g).to(dev).requires_grad_(True)
+        self.xs = [torch.randn(N, H, generator=g).to(dev).requires_grad_(True) for _ in range(L)]
+        self.gine = data.edge_attr is not None
+        self.edge_emb = [torch.randn(E, H, generator=g).to(dev).requires_grad_(True) for _ in range(L)] if self.gine else None
+        if wl["backbone"] == "PNA":
+            self.avg_deg = {"lin": 1.0, "log": 1.0}
+            width = len(PNA_AGGR) * 2 * H
+        else:
+            width = H
+        self.gouts = [torch.randn(N, width, generator=g).to(dev) for _ in range(L)]
+        self.flat = None
+        self.reuse_index = False
+
+    def attach_dp(self):
+        from dp_gsat_amd.dist import FlatGradAllReduce
+        self.flat = FlatGradAllReduce(self.ext.parameters())
+
+    def step(self):
+        G, d, wl = self.G, self.data, self.wl
+        if not self.reuse_index:
+            G.clear_cache()                       # every step is a NEW batch: re-derive CSRs / reverse perm / segments
+        if self.flat is not None:
+            self.flat.zero()
+        else:
+            for p in self.ext.parameters():
+                p.grad = None
+        self.emb.grad = None
+        index = G.get_index(d.edge_index, self.N)
+        index.graphs(d.batch, d.num_graphs)
+        M = self.E if wl["edge_att"] else self.N
+        u = torch.empty(M, 1, device=self.dev).uniform_(1e-10, 1 - 1e-10)
+        _, att = self.ext.attend(self.emb, d.edge_index, d.batch, noise=u)
+        edge_att = G.symmetrise_edge_att(att, d.edge_index, self.N) if wl["edge_att"] else G.lift_node_att_to_edge_att(att, d.edge_index)
+        outs = []
+        for l in range(wl["L"]):
+            if wl["backbone"] == "PNA":
+                outs.append(G.ops.pna_aggregate(self.xs[l], index, edge_att, None, PNA_AGGR, ["identity"], self.avg_deg))
+            else:
+                outs.append(G.ops.masked_sum_aggregate(self.xs[l], index, edge_att, self.edge_emb[l] if self.gine else None))
+        torch.autograd.backward(outs, self.gouts)
+        if self.flat is not None:
+            self.flat.all_reduce(average=True)
+
+
+class FullStep:
+    """Whole GSAT training step (example/trainer.py:28-36): forward_pass, zero_grad, backward, Adam."""
+
+    def __init__(self, wl, data, x_dim, e_dim, dev):
+        import dp_gsat_amd as G
+        from dp_gsat_amd import synth
+        self.G, self.data = G, data
+        H = wl["H"]
+        cfg = dict(model_name=wl["backbone"], n_layers=wl["L"], hidden_size=H, dropout_p=0.3, use_edge_attr=e_dim != 0,
+                   atom_encoder=data.x.dtype == torch.int64, aggregators=PNA_AGGR, scalers=False, deg=synth.in_degree_histogram(data))
+        num_class = 2 if data.y.dtype == torch.float32 else 3
+        self.clf = G.get_model(x_dim, e_dim, num_class, False, cfg, dev)
+        self.ext = G.ExtractorMLP(H, wl["edge_att"]).to(dev)
+        params = list(self.clf.parameters()) + list(self.ext.parameters())
+        self.opt = torch.optim.Adam(params, lr=1e-3, weight_decay=3e-6)
+        self.gsat = G.GSAT(self.clf, self.ext, G.Criterion(num_class, False), self.opt, learn_edge_att=wl["edge_att"]).train()
+        self.gsat.sync_loss_dict = False
+        self.flat = None
+        self.params = params
+
+    def attach_dp(self):
+        from dp_gsat_amd.dist import FlatGradAllReduce
+        self.flat = FlatGradAllReduce(self.params)
+
+    def step(self):
+        self.G.clear_cache()
+        att, loss, _, _ = self.gsat.forward_pass(self.data, 0, True)
+        if self.flat is not None:
+            self.flat.zero()
+        else:
+            self.opt.zero_grad(set_to_none=True)
+        loss.backward()
+        if self.flat is not None:
+            self.flat.all_reduce(average=True)
+        self.opt.step()
+
+
+def timed(step_fn, steps, warmup, dev, distributed):
+    for _ in range(warmup):
+        step_fn()
+    if distributed:
+        dist.barrier()
+    torch.cuda.synchronize(dev)
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        step_fn()
+    torch.cuda.synchronize(dev)
+    if distributed:
+        dist.barrier()
+    dt = time.perf_counter() - t0
+    if distributed:
+        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    return dt
+
+
+# ------------------------------------------------------------------------------------------------
+# roofline of the masked aggregation kernel: HIP events around back-to-back launches on torch's stream
+# ------------------------------------------------------------------------------------------------
+def aggregation_roofline(wl, data, dev, reps=30, rounds=5):
+    import dp_gsat_amd as G
+    from dp_gsat_amd._lib import call, ptr, stream
+    N, E, H = data.num_nodes, data.num_edges, wl["H"]
+    ix = G.get_index(data.edge_index, N)
+    x = torch.randn(N, H, device=dev)
+    att = torch.rand(E, device=dev)
+    out = {}
+    if wl["backbone"] == "PNA":
+        A, S = len(PNA_AGGR), 1
+        codes = [G.ops.AGGREGATOR_CODES[a] for a in PNA_AGGR]
+        a_arr, s_arr = (ctypes.c_int32 * A)(*codes), (ctypes.c_int32 * 1)(0)
+        y = torch.empty(N, S * A * 2 * H, device=dev)
+        def launch():
+            call("gsat_pna_fwd", ptr(x), ptr(att), None, ptr(ix.rowptr_dst), ptr(ix.src_by_dst), ptr(ix.eid_by_dst), N, H,
+                 a_arr, A, s_arr, S, 1.0, 1.0, ptr(y), stream())
+        alg_bytes = 4 * N * H + 8 * A * S * N * H + 8 * E + 4 * N        # SURVEY 8d (unfused PNA forward)
+        kname = "k_pna_fwd"
+    else:
+        y = torch.empty(N, H, device=dev)
+        ee = torch.randn(E, H, device=dev) if data.edge_attr is not None else None
+        def launch():
+            call("gsat_aggr_sum_fwd", ptr(x), None, ptr(att), ptr(ee), ptr(ix.rowptr_dst), ptr(ix.src_by_dst), ptr(ix.eid_by_dst),
+                 N, H, 1.0, ptr(y), stream())
+        alg_bytes = 8 * N * H + 8 * E + 4 * N + (4 * E * H if ee is not None else 0)   # SURVEY 8d (+ edge_emb read for GINE)
+        kname = "k_aggr_sum_fwd"
+    for _ in range(5):
+        launch()
+    torch.cuda.synchronize(dev)
+    best = []
+    for _ in range(rounds):
+        start, end = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        torch.cuda._sleep(4_000_000)              # keep the queue busy so the launches below run back to back
+        start.record()
+        for _ in range(reps):
+            launch()
+        end.record()
+        torch.cuda.synchronize(dev)
+        best.append(start.elapsed_time(end) * 1e-3 / reps)
+    t = float(np.median(best))
+    achieved = alg_bytes / t / 1e9
+    return dict(bound="hbm", kernel=kname, achieved=round(achieved, 1), peak=HBM_PEAK_GBS, unit="GB/s",
+                frac=round(achieved / HBM_PEAK_GBS, 4), traffic=None, alg_bytes_per_launch=int(alg_bytes),
+                us_per_launch=round(t * 1e6, 2), nodes=N, edges=E)
+
+
+# ------------------------------------------------------------------------------------------------
+# CPU baseline: the oracle (plain-PyTorch restatement of the reference op sequence) on the host cores
+# ------------------------------------------------------------------------------------------------
+def cpu_baseline(wl, name, seed, sample_graphs, steps=3):
+    from oracle import bookkeeping as bk
+    from oracle import modules as om
+    from oracle import ops as oops
+    from dp_gsat_amd.dist import take_graphs
+    full, _, _ = make_batch(name, wl["graphs"], seed)
+    sample_graphs = min(sample_graphs, full.num_graphs)
+    d = take_graphs(full, range(sample_graphs))
+    N, E, H, L = d.num_nodes, d.num_edges, wl["H"], wl["L"]
+    g = torch.Generator().manual_seed(seed)
+    ext = om.ExtractorMLP(H, wl["edge_att"]).train()
+    emb = torch.randn(N, H, generator=g).requires_grad_(True)
+    xs = [torch.randn(N, H, generator=g).requires_grad_(True) for _ in range(L)]
+    gine = d.edge_attr is not None
+    ees = [torch.randn(E, H, generator=g).requires_grad_(True) for _ in range(L)] if gine else None
+    width = len(PNA_AGGR) * 2 * H if wl["backbone"] == "PNA" else H
+    gouts = [torch.randn(N, width, generator=g) for _ in range(L)]
+    M = E if wl["edge_att"] else N
+    C1 = 4 * H if wl["edge_att"] else 2 * H
+
+    def step():
+        for p in ext.parameters():
+            p.grad = None
+        emb.grad = None
+        u = torch.empty(M, 1).uniform_(1e-10, 1 - 1e-10)
+        masks = [(torch.rand(M, C1) > 0.5).float(), (torch.rand(M, H) > 0.5).float()]
+        z = ext(emb, d.edge_index, d.batch, masks=masks)
+        att = oops.concrete_sample(z, u, True)
+        if wl["edge_att"]:
+            rev = torch.from_numpy(bk.reverse_edge_perm(d.edge_index, N)) if bk.is_undirected(d.edge_index, N) else None
+            edge_att = oops.symmetrise(att, rev)
+        else:
+            edge_att = oops.lift_node_att_to_edge_att(att, d.edge_index)
+        outs = []
+        for l in range(L):
+            if wl["backbone"] == "PNA":
+                outs.append(oops.pna_aggregate(xs[l], d.edge_index, edge_att, PNA_AGGR, ["identity"], {"lin": 1.0, "log": 1.0}))
+            elif gine:
+                outs.append(oops.gine_aggregate(xs[l], d.edge_index, ees[l], edge_att))
+            else:
+                outs.append(oops.gin_aggregate(xs[l], d.edge_index, edge_att))
+        torch.autograd.backward(outs, gouts)
+
+    step()
+    ts = []
+    for _ in range(steps):
+        t0 = time.perf_counter()
+        step()
+        ts.append(time.perf_counter() - t0)
+    t = float(np.median(ts))
+    return dict(value=round(E / t / 1e6, 5), unit="million edges/s", cores=int(torch.get_num_threads()), kind="port",
+                sample=f"oracle scope-A step on the first {sample_graphs} of {full.num_graphs} graphs of the workload "
+                       f"({N} nodes, {E} directed edges), 1 warm-up + median of {steps} steps, {t * 1e3:.1f} ms/step",
+                host_cpus=os.cpu_count())
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--workload", default="c3", choices=sorted(WORKLOADS))
+    ap.add_argument("--seed", type=int, default=0)
+    ap.add_argument("--reuse-index", action="store_true", help="keep the per-batch bookkeeping cached across steps")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-full-step", action="store_true")
+    ap.add_argument("--cpu-sample-graphs", type=int, default=0)
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    distributed = world > 1
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: the HIP path has no CPU fallback")
+    dev = torch.device("cuda", local_rank)
+    torch.cuda.set_device(dev)
+    if distributed:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+    if args.gpus != world and rank == 0:
+        print(f"[bench] note: --gpus {args.gpus} but WORLD_SIZE={world}; using WORLD_SIZE", file=sys.stderr)
+
+    import __graft_entry__ as ge
+    from dp_gsat_amd import _lib
+    if not os.path.exists(_lib.LIB_PATH) and rank == 0:
+        ge.build()
+    if distributed:
+        dist.barrier()
+    _lib.load()
+
+    wl = WORKLOADS[args.workload]
+    host_batch, x_dim, e_dim = local_shard(args.workload, wl["graphs"], rank, world, args.seed)
+    data = host_batch.to(dev)
+    torch.manual_seed(args.seed + rank)
+
+    hot = HotPath(wl, data, dev, seed=args.seed + rank)
+    hot.reuse_index = args.reuse_index
+    if distributed:
+        hot.attach_dp()
+    dt = timed(hot.step, args.steps, args.warmup, dev, distributed)
+    e_local = torch.tensor([float(data.num_edges), float(data.num_nodes)], dtype=torch.float64, device=dev)
+    if distributed:
+        dist.all_reduce(e_local)
+    e_total, n_total = e_local.tolist()
+    ms = dt / args.steps * 1e3
+    value = e_total / (dt / args.steps) / 1e6
+
+    full = None
+    if not args.no_full_step:
+        fs = FullStep(wl, data, x_dim, e_dim, dev)
+        if distributed:
+            fs.attach_dp()
+        fdt = timed(fs.step, max(args.steps // 2, 3), max(args.warmup // 2, 2), dev, distributed)
+        fsteps = max(args.steps // 2, 3)
+        full = dict(value=round(e_total / (fdt / fsteps) / 1e6, 3), unit="million edges/s", ms_per_step=round(fdt / fsteps * 1e3, 3),
+                    what="whole GSAT training step: 2 backbone passes + extractor + losses + backward + Adam (+ all-reduce)")
+
+    roof, cpu = None, None
+    if rank == 0:
+        hot.reuse_index = True
+        roof = aggregation_roofline(wl, data, dev)
+        if not args.no_cpu_baseline:
+            sample = args.cpu_sample_graphs or max(1, wl["graphs"] // 8)
+            cpu = cpu_baseline(wl, args.workload, args.seed, sample)
+    if distributed:
+        dist.barrier()
+
+    if rank == 0:
+        line = {
+            "metric": "million edges/s (attn+sample+aggregate fwd+bwd)", "value": round(value, 3), "unit": "million edges/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms, 4),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": wl["desc"], "graphs_per_gpu": wl["graphs"], "nodes_total": int(n_total), "edges_total": int(e_total),
+                       "hidden": wl["H"], "layers": wl["L"], "attention": "edge" if wl["edge_att"] else "node",
+                       "parallelism": f"dp{world}", "index_rebuilt_every_step": not args.reuse_index},
+            "roofline": roof, "cpu_baseline": cpu, "full_step": full,
+        }
+        if cpu:
+            line["speedup_vs_cpu_port"] = round(value / world / cpu["value"], 1) if cpu["value"] > 0 else None
+        print(json.dumps(line))
+    if distributed:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()
