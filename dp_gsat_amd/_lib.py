@@ -30,6 +30,8 @@ SIGNATURES = {
     "gsat_aggr_sum_bwd": (INT, [P, P, P, P, P, P, P, I64, I64, F32, P, P, P, P]),
     "gsat_pna_fwd": (INT, [P, P, P, P, P, P, I64, I64, P, INT, P, INT, F32, F32, P, P]),
     "gsat_pna_bwd": (INT, [P, P, P, P, P, P, P, I64, I64, P, INT, P, INT, F32, F32, P, P, P, P, P]),
+    "gsat_gemm_workspace_floats": (SZ, [INT, I64, I64, I64]),
+    "gsat_gemm_f32": (INT, [INT, INT, I64, I64, I64, P, I64, P, I64, P, I64, P, INT, P, SZ, P]),
     "gsat_attn_bwd_workspace_bytes": (SZ, [P]),
     "gsat_attn_fwd": (INT, [P, P]),
     "gsat_attn_bwd": (INT, [P, P, P]),

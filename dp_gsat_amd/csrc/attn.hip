@@ -10,7 +10,6 @@
 //     Philox dropout, the head (C2 -> 1 dot + sampler), InstanceNorm backward, deterministic column sums.
 //   * all reductions run in a fixed order (no float atomics): results are bitwise reproducible.
 #include "common.h"
-#include <rocblas/rocblas.h>
 
 namespace gsat {
 
@@ -19,31 +18,12 @@ constexpr int SB = 256;          // threads per block in the segmented kernels: 
 constexpr int SB_LANES = 16;     // lanes per row slot, one float4 each -> 64 channels per block
 constexpr int SB_SLOTS = 16;
 
-// ------------------------------------------------------------------------------------------------
-// rocBLAS plumbing: row-major C[M,N] = alpha * op(A) op(B) + beta * C
-// ------------------------------------------------------------------------------------------------
-static rocblas_handle blas_handle() {
-    static thread_local rocblas_handle h = nullptr;
-    if (!h) {
-        if (rocblas_create_handle(&h) != rocblas_status_success) { h = nullptr; return nullptr; }
-        rocblas_set_atomics_mode(h, rocblas_atomics_not_allowed);
-        rocblas_set_pointer_mode(h, rocblas_pointer_mode_host);
-    }
-    return h;
-}
-
-static int gemm_rm(hipStream_t stream, bool ta, bool tb, int64_t M, int64_t N, int64_t K, float alpha, const float* A,
-                   int64_t lda, const float* B, int64_t ldb, float beta, float* C, int64_t ldc) {
-    if (M == 0 || N == 0) return GSAT_OK;
-    rocblas_handle h = blas_handle();
-    GSAT_REQUIRE(h, GSAT_ERR_BLAS, "rocblas_create_handle failed");
-    GSAT_REQUIRE(rocblas_set_stream(h, stream) == rocblas_status_success, GSAT_ERR_BLAS, "rocblas_set_stream failed");
-    // row-major X is column-major X^T:  C^T = op(B)^T op(A)^T
-    rocblas_status st = rocblas_sgemm(h, tb ? rocblas_operation_transpose : rocblas_operation_none,
-                                      ta ? rocblas_operation_transpose : rocblas_operation_none, (rocblas_int)N, (rocblas_int)M,
-                                      (rocblas_int)K, &alpha, B, (rocblas_int)ldb, A, (rocblas_int)lda, &beta, C, (rocblas_int)ldc);
-    GSAT_REQUIRE(st == rocblas_status_success, GSAT_ERR_BLAS, "rocblas_sgemm failed with status %d", (int)st);
-    return GSAT_OK;
+// row-major C[M,N] = alpha(=1) * op(A) op(B) + beta(0|1) * C through the hand-written MFMA GEMM (gemm.hip).
+// ta: A is given as [K,M]; tb: B is given as [N,K] (nn.Linear weight layout).
+struct GemmWs { float* ptr; size_t floats; };
+static int gemm_rm(hipStream_t stream, bool ta, bool tb, int64_t M, int64_t N, int64_t K, const float* A, int64_t lda, const float* B,
+                   int64_t ldb, float beta, float* C, int64_t ldc, GemmWs ws = {nullptr, 0}) {
+    return gemm_f32(stream, ta, tb, M, N, K, A, lda, B, ldb, C, ldc, nullptr, beta != 0.f, ws.ptr, ws.floats);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -441,6 +421,12 @@ static int colsum(hipStream_t stream, const float* x, int64_t R, int C, float* o
     return GSAT_OK;
 }
 
+static size_t attn_gemm_ws_floats(const gsat_attn_args* a) {
+    const size_t w2 = gemm_workspace_floats(a->C2, a->C1, a->M, true);
+    const size_t w1 = gemm_workspace_floats(a->C1, a->H, a->N, true);
+    return w1 > w2 ? w1 : w2;
+}
+
 static int check_args(const gsat_attn_args* a, const char* who) {
     GSAT_REQUIRE(a, GSAT_ERR_ARG, "%s: null args", who);
     GSAT_REQUIRE(a->M >= 0 && a->N >= 0 && a->G >= 0 && a->M < (1ll << 31) && a->N < (1ll << 31), GSAT_ERR_ARG, "%s: bad extents", who);
@@ -474,10 +460,10 @@ int gsat_attn_fwd(const gsat_attn_args* a, void* stream_) {
     float* rstd2 = mean2 + (size_t)G * C2;
     // ---- layer 1 on nodes -------------------------------------------------------------------
     if (a->edge_mode) {
-        if ((rc = gemm_rm(stream, false, true, N, C1, H, 1.f, a->emb, H, a->W1, 2 * H, 0.f, a->P, C1))) return rc;        // P = emb W1[:, :H]^T
-        if ((rc = gemm_rm(stream, false, true, N, C1, H, 1.f, a->emb, H, a->W1 + H, 2 * H, 0.f, a->Q, C1))) return rc;    // Q = emb W1[:, H:]^T
+        if ((rc = gemm_rm(stream, false, true, N, C1, H, a->emb, H, a->W1, 2 * H, 0.f, a->P, C1))) return rc;        // P = emb W1[:, :H]^T
+        if ((rc = gemm_rm(stream, false, true, N, C1, H, a->emb, H, a->W1 + H, 2 * H, 0.f, a->Q, C1))) return rc;    // Q = emb W1[:, H:]^T
     } else {
-        if ((rc = gemm_rm(stream, false, true, N, C1, H, 1.f, a->emb, H, a->W1, H, 0.f, a->P, C1))) return rc;
+        if ((rc = gemm_rm(stream, false, true, N, C1, H, a->emb, H, a->W1, H, 0.f, a->P, C1))) return rc;
     }
     const dim3 g1((unsigned)G, (unsigned)ceil_div(C1, 64)), g2((unsigned)G, (unsigned)ceil_div(C2, 64));
     if (a->edge_mode) {
@@ -491,7 +477,7 @@ int gsat_attn_fwd(const gsat_attn_args* a, void* stream_) {
     }
     GSAT_LAUNCH_CHECK();
     // ---- layer 2 ----------------------------------------------------------------------------
-    if ((rc = gemm_rm(stream, false, true, M, C2, C1, 1.f, a->a1, C1, a->W2, C1, 0.f, a->h2, C2))) return rc;
+    if ((rc = gemm_rm(stream, false, true, M, C2, C1, a->a1, C1, a->W2, C1, 0.f, a->h2, C2))) return rc;
     {
         PreAct<false> pre{a->h2, nullptr, a->b2, nullptr, nullptr, C2};
         if (G > 0) k_seg_stats<false><<<g2, SB, 0, stream>>>(pre, a->seg_ptr, a->seg_order, mean2, rstd2);
@@ -520,6 +506,7 @@ size_t gsat_attn_bwd_workspace_bytes(const gsat_attn_args* a) {
     b += 3 * align_up(G * C2 * 4, 256);        // S1, S2, dw3 partial
     b += align_up(256 * cmax * 4, 256);        // column-sum scratch
     if (a->edge_mode) b += 2 * align_up(N * C1 * 4, 256);   // dP, dQ
+    b += align_up(attn_gemm_ws_floats(a) * 4, 256);          // split-K slabs of the weight-gradient GEMMs
     return b + 1024;
 }
 
@@ -556,6 +543,8 @@ int gsat_attn_bwd(const gsat_attn_args* a, const gsat_attn_grads* gr, void* stre
     float* scratch = ar.take<float>((size_t)256 * std::max(C1, C2));
     float *dP = nullptr, *dQ = nullptr;
     if (a->edge_mode) { dP = ar.take<float>((size_t)N * C1); dQ = ar.take<float>((size_t)N * C1); }
+    GemmWs gws{nullptr, attn_gemm_ws_floats(a)};
+    gws.ptr = ar.take<float>(gws.floats);
     GSAT_REQUIRE(ar.ok(), GSAT_ERR_WORKSPACE, "gsat_attn_bwd: workspace %zu < %zu", gr->workspace_bytes, ar.off);
     float* mean1 = a->stats;
     float* rstd1 = mean1 + (size_t)G * C1;
@@ -580,8 +569,8 @@ int gsat_attn_bwd(const gsat_attn_args* a, const gsat_attn_grads* gr, void* stre
     GSAT_CHECK_HIP(hipMemsetAsync(gr->db2, 0, sizeof(float) * C2, stream));
     GSAT_CHECK_HIP(hipMemsetAsync(gr->db1, 0, sizeof(float) * C1, stream));
     // dW2[C2,C1] = dh2^T a1 ; da1[M,C1] = dh2 W2
-    if ((rc = gemm_rm(stream, true, false, C2, C1, M, 1.f, dh2, C2, a->a1, C1, 0.f, gr->dW2, C1))) return rc;
-    if ((rc = gemm_rm(stream, false, false, M, C1, C2, 1.f, dh2, C2, a->W2, C1, 0.f, da1, C1))) return rc;
+    if ((rc = gemm_rm(stream, true, false, C2, C1, M, dh2, C2, a->a1, C1, 0.f, gr->dW2, C1, gws))) return rc;
+    if ((rc = gemm_rm(stream, false, false, M, C1, C2, dh2, C2, a->W2, C1, 0.f, da1, C1))) return rc;
     // ---- through ReLU/dropout and the first InstanceNorm ---------------------------------------
     k_l1_bwd_stats<<<g1, SB, 0, stream>>>(da1, a->a1, a->seg_ptr, a->seg_order, sc, C1, S1p, S2p);
     GSAT_LAUNCH_CHECK();
@@ -594,16 +583,16 @@ int gsat_attn_bwd(const gsat_attn_args* a, const gsat_attn_grads* gr, void* stre
         k_rows_by_eid<<<nbn, 256, 0, stream>>>(da1, gr->rowptr_dst, gr->eid_by_dst, (int)N, C1, dQ);
         GSAT_LAUNCH_CHECK();
         // demb = dP W1a + dQ W1b ; dW1[:, :H] = dP^T emb ; dW1[:, H:] = dQ^T emb
-        if ((rc = gemm_rm(stream, false, false, N, H, C1, 1.f, dP, C1, a->W1, 2 * H, 0.f, gr->demb, H))) return rc;
-        if ((rc = gemm_rm(stream, false, false, N, H, C1, 1.f, dQ, C1, a->W1 + H, 2 * H, 1.f, gr->demb, H))) return rc;
-        if ((rc = gemm_rm(stream, true, false, C1, H, N, 1.f, dP, C1, a->emb, H, 0.f, gr->dW1, 2 * H))) return rc;
-        if ((rc = gemm_rm(stream, true, false, C1, H, N, 1.f, dQ, C1, a->emb, H, 0.f, gr->dW1 + H, 2 * H))) return rc;
+        if ((rc = gemm_rm(stream, false, false, N, H, C1, dP, C1, a->W1, 2 * H, 0.f, gr->demb, H))) return rc;
+        if ((rc = gemm_rm(stream, false, false, N, H, C1, dQ, C1, a->W1 + H, 2 * H, 1.f, gr->demb, H))) return rc;
+        if ((rc = gemm_rm(stream, true, false, C1, H, N, dP, C1, a->emb, H, 0.f, gr->dW1, 2 * H, gws))) return rc;
+        if ((rc = gemm_rm(stream, true, false, C1, H, N, dQ, C1, a->emb, H, 0.f, gr->dW1 + H, 2 * H, gws))) return rc;
     } else {
         PreAct<false> pre{a->P, nullptr, a->b1, nullptr, nullptr, C1};
         k_dh1<false><<<ew_blocks(M * (C1 / 4)), 256, 0, stream>>>(pre, a->row_seg, mean1, rstd1, a->a1, sc, S1p, S2p, M, da1);
         GSAT_LAUNCH_CHECK();
-        if ((rc = gemm_rm(stream, false, false, N, H, C1, 1.f, da1, C1, a->W1, H, 0.f, gr->demb, H))) return rc;
-        if ((rc = gemm_rm(stream, true, false, C1, H, N, 1.f, da1, C1, a->emb, H, 0.f, gr->dW1, H))) return rc;
+        if ((rc = gemm_rm(stream, false, false, N, H, C1, da1, C1, a->W1, H, 0.f, gr->demb, H))) return rc;
+        if ((rc = gemm_rm(stream, true, false, C1, H, N, da1, C1, a->emb, H, 0.f, gr->dW1, H, gws))) return rc;
     }
     return GSAT_OK;
 }

@@ -51,6 +51,11 @@ struct Arena {
     bool ok() const { return base != nullptr && off <= cap; }
 };
 
+// ---- fp32 MFMA GEMM (gemm.hip): C[M,N] (+)= op(A) op(B) (+ bias) --------------------------------
+int gemm_f32(hipStream_t stream, bool a_t, bool b_t, int64_t M, int64_t N, int64_t K, const float* A, int64_t lda, const float* B,
+             int64_t ldb, float* C, int64_t ldc, const float* bias, bool accumulate, float* ws, size_t ws_floats);
+size_t gemm_workspace_floats(int64_t M, int64_t N, int64_t K, bool reduce_rows);
+
 // ---- device helpers -------------------------------------------------------------------------
 #ifdef __HIPCC__
 constexpr int WAVE = 64;

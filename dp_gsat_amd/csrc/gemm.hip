@@ -1,0 +1,209 @@
+// fp32-input MFMA GEMM for the attention extractor (gfx950: v_mfma_f32_32x32x2_f32, exact fp32 FMA chain,
+// 64 FLOP/clk/SIMD).  Shapes here are tall and skinny (rows = nodes/edges, 16..1024 channels), where the
+// vendor sgemm heuristics pick poor kernels (1.4 ms for a 51k x 256 x 128 product, profiles/r01_c3_*).
+//
+// Tile: 128 x 128 x 32 per 256-thread workgroup, 4 wavefronts as 2 x 2, each 64 x 64 = 2 x 2 MFMA tiles
+// (64 accumulator registers).  Operands are staged global -> registers -> LDS with the next K-slab's loads
+// in flight under the current slab's MFMAs (two LDS buffers, one barrier per slab).  LDS images are
+// k-major ([k][m] and [k][n], row stride 132 floats) so an MFMA operand fetch is one conflict-free
+// ds_read_b32 per lane.
+//
+// Three operand layouts cover forward, backward-data and backward-weight:
+//   A_T = false: A is [M,K] row-major (k contiguous)      A_T = true: A is [K,M] row-major (reduction-major)
+//   B_T = true : B is [N,K] row-major (nn.Linear weight)  B_T = false: B is [K,N] row-major
+// Weight gradients reduce over the row dimension (K = #rows, huge; M x N small): blockIdx.z splits K and
+// writes partial slabs that a second kernel sums in slab order (deterministic, no atomics).
+#include "common.h"
+
+namespace gsat {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+constexpr int GM = 128, GN = 128, GK = 32, GT = 256;
+constexpr int LD_KC = 129;   // k-contiguous source: transposing scalar stores, odd stride -> conflict-free
+constexpr int LD_KM = 132;   // k-major source: 16-byte vector stores need a multiple of 4
+
+// stage one 128(rows) x 32(k) slab of a k-contiguous operand:  4 float4 per thread
+struct StageKC { float4 v[4]; };
+// X[r][k], r in [r0, r0+128), k in [k0, k0+32): thread t -> row (t>>3) + 32p, k-quad t&7
+__device__ __forceinline__ void load_kcontig(StageKC& s, const float* __restrict__ X, int64_t ld, int r0, int R, int k0, int K, int t) {
+    const int kq = (t & 7) * 4;
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+        const int r = r0 + (t >> 3) + 32 * p;
+        s.v[p] = (r < R && k0 + kq < K) ? ld4(X + (size_t)r * ld + k0 + kq) : f4zero();
+    }
+}
+__device__ __forceinline__ void store_kcontig(const StageKC& s, float* __restrict__ L, int t) {   // L[k][LD_KC]
+    const int kq = (t & 7) * 4;
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+        const int r = (t >> 3) + 32 * p;
+        L[(kq + 0) * LD_KC + r] = s.v[p].x;
+        L[(kq + 1) * LD_KC + r] = s.v[p].y;
+        L[(kq + 2) * LD_KC + r] = s.v[p].z;
+        L[(kq + 3) * LD_KC + r] = s.v[p].w;
+    }
+}
+// X[k][c], k in [k0,k0+32), c in [c0,c0+128): thread t -> k (t>>5) + 8p, column quad t&31
+__device__ __forceinline__ void load_kmajor(StageKC& s, const float* __restrict__ X, int64_t ld, int c0, int Ccols, int k0, int K, int t) {
+    const int cq = (t & 31) * 4;
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+        const int k = k0 + (t >> 5) + 8 * p;
+        s.v[p] = (k < K && c0 + cq < Ccols) ? ld4(X + (size_t)k * ld + c0 + cq) : f4zero();
+    }
+}
+__device__ __forceinline__ void store_kmajor(const StageKC& s, float* __restrict__ L, int t) {
+    const int cq = (t & 31) * 4;
+#pragma unroll
+    for (int p = 0; p < 4; ++p) st4(L + ((t >> 5) + 8 * p) * LD_KM + cq, s.v[p]);
+}
+
+template <bool A_T, bool B_T>
+__global__ __launch_bounds__(GT) void k_gemm_f32(const float* __restrict__ A, int64_t lda, const float* __restrict__ B, int64_t ldb,
+                                                 float* __restrict__ C, int64_t ldc, int M, int N, int K, int k_per_split,
+                                                 const float* __restrict__ bias, int accumulate, size_t slab_stride) {
+    constexpr int LDA = A_T ? LD_KM : LD_KC, LDB = B_T ? LD_KC : LD_KM;
+    __shared__ __attribute__((aligned(16))) float As[GK * LDA];
+    __shared__ __attribute__((aligned(16))) float Bs[GK * LDB];
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int m0 = blockIdx.y * GM, n0 = blockIdx.x * GN;
+    const int kbeg = blockIdx.z * k_per_split, kend = min(K, kbeg + k_per_split);
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    StageKC sa, sb;
+    auto gload = [&](int k0) {
+        if (A_T) load_kmajor(sa, A, lda, m0, M, k0, kend, t); else load_kcontig(sa, A, lda, m0, M, k0, kend, t);
+        if (B_T) load_kcontig(sb, B, ldb, n0, N, k0, kend, t); else load_kmajor(sb, B, ldb, n0, N, k0, kend, t);
+    };
+    auto lstore = [&]() {
+        if (A_T) store_kmajor(sa, As, t); else store_kcontig(sa, As, t);
+        if (B_T) store_kcontig(sb, Bs, t); else store_kmajor(sb, Bs, t);
+    };
+    if (kbeg < kend) {
+        gload(kbeg);
+        lstore();
+    }
+    __syncthreads();
+    const int arow = wm * 64 + (lane & 31), bcol = wn * 64 + (lane & 31), kh = lane >> 5;
+    for (int k0 = kbeg; k0 < kend; k0 += GK) {
+        const bool more = k0 + GK < kend;
+        if (more) gload(k0 + GK);                       // next slab's global loads fly under this slab's MFMAs
+#pragma unroll
+        for (int kk = 0; kk < GK / 2; ++kk) {
+            const int ka = (2 * kk + kh) * LDA, kb = (2 * kk + kh) * LDB;
+            const float a0 = As[ka + arow], a1 = As[ka + arow + 32];
+            const float b0 = Bs[kb + bcol], b1 = Bs[kb + bcol + 32];
+            acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc[0][0], 0, 0, 0);
+            acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, acc[0][1], 0, 0, 0);
+            acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc[1][0], 0, 0, 0);
+            acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc[1][1], 0, 0, 0);
+        }
+        __syncthreads();                                // every wave is done reading this slab
+        if (more) lstore();
+        __syncthreads();
+    }
+    // ---- epilogue: C/D map of the 32x32 MFMA: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5) ----------
+    float* Cb = C + (size_t)blockIdx.z * slab_stride;
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int col = n0 + wn * 64 + j * 32 + (lane & 31);
+            if (col >= N) continue;
+            const float bv = bias ? bias[col] : 0.f;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = m0 + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * kh;
+                if (row < M) {
+                    float* p = Cb + (size_t)row * ldc + col;
+                    float v = acc[i][j][r] + bv;
+                    *p = accumulate ? *p + v : v;
+                }
+            }
+        }
+}
+
+// out[i] = (accumulate ? out[i] : 0) + sum_s slabs[s][i], slabs summed in order
+__global__ void k_slab_reduce(const float* __restrict__ slabs, int nslab, size_t slab_stride, int M, int N, int64_t ldc,
+                              int accumulate, float* __restrict__ out) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (int64_t)M * N) return;
+    const int r = (int)(i / N), c = (int)(i % N);
+    float acc = 0.f;
+    for (int s = 0; s < nslab; ++s) acc += slabs[(size_t)s * slab_stride + (size_t)r * N + c];
+    float* p = out + (size_t)r * ldc + c;
+    *p = accumulate ? *p + acc : acc;
+}
+
+// number of K splits used for an M x N output reduced over K rows (shared by the workspace query)
+int gemm_splits(int64_t M, int64_t N, int64_t K, bool reduce_rows) {
+    if (!reduce_rows) return 1;                       // only weight gradients (K = #rows) are split
+    const int64_t tiles = ceil_div(M, GM) * ceil_div(N, GN);
+    if (tiles >= 256 || K <= 4 * GK) return 1;
+    int64_t s = std::min<int64_t>(ceil_div(1024, tiles), ceil_div(K, 8 * GK));
+    return (int)std::max<int64_t>(1, std::min<int64_t>(s, 512));
+}
+
+size_t gemm_workspace_floats(int64_t M, int64_t N, int64_t K, bool reduce_rows) {
+    const int s = gemm_splits(M, N, K, reduce_rows);
+    return s > 1 ? (size_t)s * M * N : 0;
+}
+
+// C[M,N] (+)= op(A) op(B) (+ bias).  a_t: A given as [K,M]; b_t: B given as [N,K].  K % 4 == 0 and the
+// contiguous extents must be multiples of 4 (float4 staging).  `ws` is needed when gemm_splits() > 1.
+int gemm_f32(hipStream_t stream, bool a_t, bool b_t, int64_t M, int64_t N, int64_t K, const float* A, int64_t lda, const float* B,
+             int64_t ldb, float* C, int64_t ldc, const float* bias, bool accumulate, float* ws, size_t ws_floats) {
+    if (M <= 0 || N <= 0) return GSAT_OK;
+    GSAT_REQUIRE(K > 0 && A && B && C, GSAT_ERR_ARG, "gemm_f32: bad argument");
+    GSAT_REQUIRE(lda % 4 == 0 && ldb % 4 == 0 && (a_t ? M % 4 == 0 : K % 4 == 0) && (b_t ? K % 4 == 0 : N % 4 == 0), GSAT_ERR_UNSUPPORTED,
+                 "gemm_f32: contiguous extents and leading dimensions must be multiples of 4 (M=%lld N=%lld K=%lld)", (long long)M, (long long)N, (long long)K);
+    GSAT_REQUIRE(((uintptr_t)A % 16 == 0) && ((uintptr_t)B % 16 == 0), GSAT_ERR_ARG, "gemm_f32: operands must be 16-byte aligned");
+    const int splits = gemm_splits(M, N, K, a_t);
+    dim3 grid((unsigned)ceil_div(N, GN), (unsigned)ceil_div(M, GM), (unsigned)splits);
+    int kps = (int)(ceil_div(ceil_div(K, splits), GK) * GK);
+    float* out = C;
+    int64_t ldo = ldc;
+    size_t slab = 0;
+    int acc_flag = accumulate ? 1 : 0;
+    const float* bptr = bias;
+    if (splits > 1) {
+        GSAT_REQUIRE(ws && ws_floats >= (size_t)splits * M * N, GSAT_ERR_WORKSPACE, "gemm_f32: split-K workspace too small");
+        GSAT_REQUIRE(!bias, GSAT_ERR_UNSUPPORTED, "gemm_f32: bias with split-K");
+        out = ws; ldo = N; slab = (size_t)M * N; acc_flag = 0;
+    }
+#define LAUNCH(AT, BT) k_gemm_f32<AT, BT><<<grid, GT, 0, stream>>>(A, lda, B, ldb, out, ldo, (int)M, (int)N, (int)K, kps, bptr, acc_flag, slab)
+    if (a_t) { if (b_t) LAUNCH(true, true); else LAUNCH(true, false); }
+    else { if (b_t) LAUNCH(false, true); else LAUNCH(false, false); }
+#undef LAUNCH
+    GSAT_LAUNCH_CHECK();
+    if (splits > 1) {
+        k_slab_reduce<<<(unsigned)ceil_div(M * N, 256), 256, 0, stream>>>(ws, splits, slab, (int)M, (int)N, ldc, accumulate ? 1 : 0, C);
+        GSAT_LAUNCH_CHECK();
+    }
+    return GSAT_OK;
+}
+
+}  // namespace gsat
+
+using namespace gsat;
+
+extern "C" {
+
+/* C[M,N] = (accumulate ? C : 0) + op(A) op(B) + bias ; see include/gsat_hip.h */
+int gsat_gemm_f32(int a_t, int b_t, int64_t M, int64_t N, int64_t K, const float* A, int64_t lda, const float* B, int64_t ldb,
+                  float* C, int64_t ldc, const float* bias, int accumulate, float* workspace, size_t workspace_floats, void* stream) {
+    return gemm_f32((hipStream_t)stream, a_t != 0, b_t != 0, M, N, K, A, lda, B, ldb, C, ldc, bias, accumulate != 0, workspace, workspace_floats);
+}
+
+size_t gsat_gemm_workspace_floats(int a_t, int64_t M, int64_t N, int64_t K) { return gemm_workspace_floats(M, N, K, a_t != 0); }
+
+}  // extern "C"

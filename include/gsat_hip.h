@@ -159,6 +159,21 @@ int gsat_pna_bwd(const float* x, const float* att, const float* edge_emb, const 
                  float avg_deg_lin, float avg_deg_log, float* dx_self, float* dmsg, float* datt,
                  float* dedge_emb, void* stream);
 
+/* ================================ dense fp32 MFMA GEMM ======================================== */
+
+/*
+ * C[M,N] = (accumulate ? C : 0) + op(A) op(B) + bias,   exact fp32 (v_mfma_f32_32x32x2_f32).
+ *   a_t == 0: A is [M,K] row-major;  a_t != 0: A is [K,M] row-major (reduction over rows, split-K slabs)
+ *   b_t != 0: B is [N,K] row-major (nn.Linear weight);  b_t == 0: B is [K,N] row-major
+ * replaces: the `addmm` launches of nn.Linear inside the attention MLP (src/utils/get_model.py:61).
+ * Contiguous extents and leading dimensions must be multiples of 4; workspace (floats) from
+ * gsat_gemm_workspace_floats() is only needed when a_t != 0; bias (nullable, [N]) only when a_t == 0.
+ */
+size_t gsat_gemm_workspace_floats(int a_t, int64_t M, int64_t N, int64_t K);
+int gsat_gemm_f32(int a_t, int b_t, int64_t M, int64_t N, int64_t K, const float* A, int64_t lda,
+                  const float* B, int64_t ldb, float* C, int64_t ldc, const float* bias, int accumulate,
+                  float* workspace, size_t workspace_floats, void* stream);
+
 /* =============================== attention extractor MLP ===================================== */
 
 /*

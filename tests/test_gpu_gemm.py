@@ -1,0 +1,56 @@
+"""-m gpu: the hand-written fp32 MFMA GEMM (all operand layouts, ragged sizes, split-K) vs torch.matmul in fp64."""
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _run(dev, a_t, b_t, M, N, K, bias=False, accumulate=False):
+    from dp_gsat_amd._lib import call, load, ptr, stream
+    g = torch.Generator().manual_seed(M * 7 + N * 3 + K)
+    A = torch.randn((K, M) if a_t else (M, K), generator=g)
+    B = torch.randn((N, K) if b_t else (K, N), generator=g)
+    C0 = torch.randn(M, N, generator=g)
+    bv = torch.randn(N, generator=g) if bias else None
+    ref = (A.double().t() if a_t else A.double()) @ (B.double().t() if b_t else B.double())
+    if bias:
+        ref = ref + bv.double()
+    if accumulate:
+        ref = ref + C0.double()
+    Ad, Bd, Cd = A.to(dev), B.to(dev), C0.to(dev).clone()
+    bd = bv.to(dev) if bias else None
+    wsf = int(load().gsat_gemm_workspace_floats(int(a_t), M, N, K))
+    ws = torch.empty(max(wsf, 1), device=dev)
+    call("gsat_gemm_f32", int(a_t), int(b_t), M, N, K, ptr(Ad), Ad.shape[1], ptr(Bd), Bd.shape[1], ptr(Cd), N, ptr(bd),
+         int(accumulate), ptr(ws), wsf, stream())
+    err = (Cd.cpu().double() - ref).abs().max().item()
+    assert err <= 2e-6 * K ** 0.5 * max(1.0, ref.abs().max().item()), (err, a_t, b_t, M, N, K)
+
+
+@pytest.mark.parametrize("a_t,b_t", [(False, True), (False, False), (True, False), (True, True)])
+@pytest.mark.parametrize("M,N,K", [(128, 128, 32), (1000, 256, 128), (77, 20, 36), (4, 4, 4), (513, 132, 260), (3001, 64, 64)])
+def test_gemm_layouts(dev, a_t, b_t, M, N, K):
+    if a_t and M % 4:
+        M += 4 - M % 4
+    if not b_t and N % 4:
+        N += 4 - N % 4
+    _run(dev, a_t, b_t, M, N, K)
+
+
+def test_gemm_bias_accumulate_and_splitk(dev):
+    _run(dev, False, True, 300, 96, 64, bias=True)
+    _run(dev, False, False, 300, 96, 64, accumulate=True)
+    _run(dev, True, False, 128, 256, 50000)            # weight-gradient shape: split-K slabs + ordered reduce
+    _run(dev, True, False, 512, 128, 20000, accumulate=True)
+
+
+def test_gemm_deterministic(dev):
+    from dp_gsat_amd._lib import call, load, ptr, stream
+    A = torch.randn(30000, 128, device=dev); B = torch.randn(30000, 256, device=dev)
+    wsf = int(load().gsat_gemm_workspace_floats(1, 128, 256, 30000))
+    outs = []
+    for _ in range(2):
+        C = torch.empty(128, 256, device=dev); ws = torch.empty(wsf, device=dev)
+        call("gsat_gemm_f32", 1, 0, 128, 256, 30000, ptr(A), 128, ptr(B), 256, ptr(C), 256, None, 0, ptr(ws), wsf, stream())
+        outs.append(C)
+    assert torch.equal(outs[0], outs[1])
