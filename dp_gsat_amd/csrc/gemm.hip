@@ -132,14 +132,22 @@ __global__ __launch_bounds__(GT) void k_gemm_f32(const float* __restrict__ A, in
         }
 }
 
-// out[i] = (accumulate ? out[i] : 0) + sum_s slabs[s][i], slabs summed in order
+// out[i] = (accumulate ? out[i] : 0) + sum_s slabs[s][i].  Eight independent partial sums (slab s goes to
+// partial s % 8) keep eight loads in flight; the order is fixed, so the result is bitwise reproducible.
 __global__ void k_slab_reduce(const float* __restrict__ slabs, int nslab, size_t slab_stride, int M, int N, int64_t ldc,
                               int accumulate, float* __restrict__ out) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= (int64_t)M * N) return;
+    const float* p0 = slabs + i;
+    float a[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    int s = 0;
+    for (; s + 8 <= nslab; s += 8) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) a[j] += p0[(size_t)(s + j) * slab_stride];
+    }
+    for (int j = 0; s < nslab; ++s, ++j) a[j] += p0[(size_t)s * slab_stride];
+    const float acc = ((a[0] + a[1]) + (a[2] + a[3])) + ((a[4] + a[5]) + (a[6] + a[7]));
     const int r = (int)(i / N), c = (int)(i % N);
-    float acc = 0.f;
-    for (int s = 0; s < nslab; ++s) acc += slabs[(size_t)s * slab_stride + (size_t)r * N + c];
     float* p = out + (size_t)r * ldc + c;
     *p = accumulate ? *p + acc : acc;
 }
