@@ -26,12 +26,16 @@ SIGNATURES = {
     "gsat_reverse_edge_perm": (INT, [P, I64, I64, P, P, P, SZ, P]),
     "gsat_segment_ptr": (INT, [P, I64, I64, P, P, P]),
     "gsat_gather_i64": (INT, [P, P, I64, P, P]),
-    "gsat_aggr_sum_fwd": (INT, [P, P, P, P, P, P, P, I64, I64, F32, P, P]),
-    "gsat_aggr_sum_bwd": (INT, [P, P, P, P, P, P, P, I64, I64, F32, P, P, P, P]),
+    "gsat_row_chunks_workspace_bytes": (SZ, [I64]),
+    "gsat_row_chunks": (INT, [P, I64, P, P, SZ, P]),
+    "gsat_long_row_partial_floats": (SZ, [I64, I64]),
+    "gsat_aggr_sum_fwd": (INT, [P, P, P, P, P, P, P, I64, I64, I64, F32, P, P, P, P]),
+    "gsat_aggr_sum_bwd": (INT, [P, P, P, P, P, P, P, I64, I64, I64, F32, P, P, P, P, P, P]),
     "gsat_pna_fwd": (INT, [P, P, P, P, P, P, I64, I64, P, INT, P, INT, F32, F32, P, P]),
     "gsat_pna_bwd": (INT, [P, P, P, P, P, P, P, I64, I64, P, INT, P, INT, F32, F32, P, P, P, P, P]),
     "gsat_gemm_workspace_floats": (SZ, [INT, I64, I64, I64]),
     "gsat_gemm_f32": (INT, [INT, INT, I64, I64, I64, P, I64, P, I64, P, I64, P, INT, P, SZ, P]),
+    "gsat_attn_fwd_workspace_bytes": (SZ, [P]),
     "gsat_attn_bwd_workspace_bytes": (SZ, [P]),
     "gsat_attn_fwd": (INT, [P, P]),
     "gsat_attn_bwd": (INT, [P, P, P]),
@@ -59,12 +63,14 @@ class AttnArgs(ctypes.Structure):
                 ("src", P), ("dst", P), ("seg_ptr", P), ("seg_order", P), ("row_seg", P),
                 ("W1", P), ("b1", P), ("W2", P), ("b2", P), ("W3", P), ("b3", P),
                 ("emb", P), ("mask1", P), ("mask2", P), ("u", P),
-                ("P", P), ("Q", P), ("a1", P), ("h2", P), ("stats", P), ("logits", P), ("att", P)]
+                ("P", P), ("Q", P), ("a1", P), ("h2", P), ("stats", P), ("logits", P), ("att", P),
+                ("fwd_workspace", P), ("fwd_workspace_bytes", SZ)]
 
 
 class AttnGrads(ctypes.Structure):
     """mirror of `gsat_attn_grads` (include/gsat_hip.h)."""
     _fields_ = [("dlogits", P), ("datt", P), ("rowptr_src", P), ("eid_by_src", P), ("rowptr_dst", P), ("eid_by_dst", P),
+                ("chunk_ptr_src", P), ("chunk_ptr_dst", P),
                 ("demb", P), ("dW1", P), ("db1", P), ("dW2", P), ("db2", P), ("dW3", P), ("db3", P),
                 ("workspace", P), ("workspace_bytes", SZ)]
 

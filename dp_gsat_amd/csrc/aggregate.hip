@@ -11,6 +11,7 @@
 namespace gsat {
 
 constexpr int AGG_BLOCK = 256;
+constexpr int CH = GSAT_LONG_ROW_EDGES;   // rows with more in-edges than this are split into CH-edge chunks
 
 // Logical block id such that the blocks resident on one XCD (b % 8 equal) cover a contiguous range.
 __device__ __forceinline__ int xcd_remap(int b, int nb) {
@@ -22,7 +23,8 @@ template <int LPR, int NV, bool GINE>
 __global__ __launch_bounds__(AGG_BLOCK) void k_aggr_sum_fwd(
     const float* __restrict__ x, const float* __restrict__ self_rows, const float* __restrict__ att,
     const float* __restrict__ edge_emb, const int32_t* __restrict__ rowptr, const int32_t* __restrict__ col,
-    const int32_t* __restrict__ eid, int num_rows, int H, float self_coef, float* __restrict__ out, int rows_per_group) {
+    const int32_t* __restrict__ eid, int num_rows, int H, float self_coef, float* __restrict__ out, int rows_per_group,
+    const int32_t* __restrict__ chunk_ptr, const float* __restrict__ partial) {
     constexpr int GPB = AGG_BLOCK / LPR;
     const int lane = threadIdx.x % LPR;
     const int grp = xcd_remap(blockIdx.x, gridDim.x) * GPB + threadIdx.x / LPR;
@@ -35,10 +37,28 @@ __global__ __launch_bounds__(AGG_BLOCK) void k_aggr_sum_fwd(
         for (int v = 0; v < NV; ++v) {
             int c = (v * LPR + lane) * 4;
             acc[v] = f4zero();
-            if (c < H) {
+            if (c < H && self_coef != 0.f) {
                 float4 s = ld4(self_rows + (size_t)row * H + c);
                 acc[v] = make_float4(self_coef * s.x, self_coef * s.y, self_coef * s.z, self_coef * s.w);
             }
+        }
+        if (chunk_ptr != nullptr && end - beg > CH) {      // long row: add the chunk partials in chunk order
+            for (int p = chunk_ptr[row]; p < chunk_ptr[row + 1]; ++p) {
+#pragma unroll
+                for (int v = 0; v < NV; ++v) {
+                    int c = (v * LPR + lane) * 4;
+                    if (c < H) {
+                        float4 t = ld4(partial + (size_t)p * H + c);
+                        acc[v].x += t.x; acc[v].y += t.y; acc[v].z += t.z; acc[v].w += t.w;
+                    }
+                }
+            }
+#pragma unroll
+            for (int v = 0; v < NV; ++v) {
+                int c = (v * LPR + lane) * 4;
+                if (c < H) st4(out + (size_t)row * H + c, acc[v]);
+            }
+            continue;
         }
         int k = beg;
         for (; k + 2 <= end; k += 2) {   // two gathered rows in flight per group
@@ -94,7 +114,8 @@ __global__ __launch_bounds__(AGG_BLOCK) void k_aggr_sum_bwd(
     const float* __restrict__ x, const float* __restrict__ att, const float* __restrict__ edge_emb,
     const float* __restrict__ dout, const int32_t* __restrict__ rowptr, const int32_t* __restrict__ dstc,
     const int32_t* __restrict__ eid, int num_rows, int H, float self_coef, float* __restrict__ dx,
-    float* __restrict__ datt, float* __restrict__ dedge, int rows_per_group) {
+    float* __restrict__ datt, float* __restrict__ dedge, int rows_per_group, const int32_t* __restrict__ chunk_ptr,
+    const float* __restrict__ partial) {
     constexpr int GPB = AGG_BLOCK / LPR;
     const int lane = threadIdx.x % LPR;
     const int grp = xcd_remap(blockIdx.x, gridDim.x) * GPB + threadIdx.x / LPR;
@@ -102,6 +123,22 @@ __global__ __launch_bounds__(AGG_BLOCK) void k_aggr_sum_bwd(
     const int row_end = min(num_rows, row + rows_per_group);
     for (; row < row_end; ++row) {
         const int beg = rowptr[row], end = rowptr[row + 1];
+        if (chunk_ptr != nullptr && end - beg > CH) {      // long row: per-edge outputs were written by the chunk kernel
+#pragma unroll
+            for (int v = 0; v < NV; ++v) {
+                int c = (v * LPR + lane) * 4;
+                if (c < H) {
+                    float4 g = ld4(dout + (size_t)row * H + c);
+                    float4 a = make_float4(self_coef * g.x, self_coef * g.y, self_coef * g.z, self_coef * g.w);
+                    for (int p = chunk_ptr[row]; p < chunk_ptr[row + 1]; ++p) {
+                        float4 t = ld4(partial + (size_t)p * H + c);
+                        a.x += t.x; a.y += t.y; a.z += t.z; a.w += t.w;
+                    }
+                    st4(dx + (size_t)row * H + c, a);
+                }
+            }
+            continue;
+        }
         float4 acc[NV], xj[NV];
 #pragma unroll
         for (int v = 0; v < NV; ++v) {
@@ -145,6 +182,144 @@ __global__ __launch_bounds__(AGG_BLOCK) void k_aggr_sum_bwd(
         for (int v = 0; v < NV; ++v) {
             int c = (v * LPR + lane) * 4;
             if (c < H) st4(dx + (size_t)row * H + c, acc[v]);
+        }
+    }
+}
+
+
+// item i of the chunk list -> (row, first slot, last slot): row = the r with chunk_ptr[r] <= i < chunk_ptr[r+1]
+__device__ __forceinline__ void chunk_item(const int32_t* __restrict__ chunk_ptr, const int32_t* __restrict__ rowptr, int num_rows,
+                                           int item, int* row, int* beg, int* end) {
+    int lo = 0, hi = num_rows;                   // invariant: chunk_ptr[lo] <= item < chunk_ptr[hi]
+    while (hi - lo > 1) {
+        int mid = (lo + hi) >> 1;
+        if (chunk_ptr[mid] <= item) lo = mid; else hi = mid;
+    }
+    *row = lo;
+    *beg = rowptr[lo] + (item - chunk_ptr[lo]) * CH;
+    *end = min(rowptr[lo + 1], *beg + CH);
+}
+
+// Long rows, forward: one lane group sums one CH-edge chunk into partial[item,:] (no self term).
+template <int LPR, int NV, bool GINE>
+__global__ __launch_bounds__(AGG_BLOCK) void k_aggr_chunk_fwd(
+    const float* __restrict__ x, const float* __restrict__ att, const float* __restrict__ edge_emb,
+    const int32_t* __restrict__ rowptr, const int32_t* __restrict__ col, const int32_t* __restrict__ eid, int num_rows, int H,
+    const int32_t* __restrict__ chunk_ptr, float* __restrict__ partial) {
+    constexpr int GPB = AGG_BLOCK / LPR;
+    const int lane = threadIdx.x % LPR;
+    const int total = chunk_ptr[num_rows];
+    for (int item = blockIdx.x * GPB + threadIdx.x / LPR; item < total; item += gridDim.x * GPB) {
+        int row, beg, end;
+        chunk_item(chunk_ptr, rowptr, num_rows, item, &row, &beg, &end);
+        float4 acc[NV];
+#pragma unroll
+        for (int v = 0; v < NV; ++v) acc[v] = f4zero();
+        int k = beg;
+        for (; k + 4 <= end; k += 4) {             // four gathered rows in flight (hub chunks are latency-bound otherwise)
+            int j[4], e[4];
+            float w[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                j[u] = col[k + u];
+                e[u] = (att != nullptr || GINE) ? eid[k + u] : 0;
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) w[u] = att ? att[e[u]] : 1.f;
+#pragma unroll
+            for (int v = 0; v < NV; ++v) {
+                int c = (v * LPR + lane) * 4;
+                if (c < H) {
+                    float4 a[4];
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) a[u] = ld4(x + (size_t)j[u] * H + c);
+                    if (GINE) {
+#pragma unroll
+                        for (int u = 0; u < 4; ++u) {
+                            float4 ea = ld4(edge_emb + (size_t)e[u] * H + c);
+                            a[u] = make_float4(fmaxf(a[u].x + ea.x, 0.f), fmaxf(a[u].y + ea.y, 0.f), fmaxf(a[u].z + ea.z, 0.f), fmaxf(a[u].w + ea.w, 0.f));
+                        }
+                    }
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) acc[v] = f4fma(w[u], a[u], acc[v]);
+                }
+            }
+        }
+        for (; k < end; ++k) {
+            const int j = col[k];
+            const int e = (att != nullptr || GINE) ? eid[k] : 0;
+            const float w = att ? att[e] : 1.f;
+#pragma unroll
+            for (int v = 0; v < NV; ++v) {
+                int c = (v * LPR + lane) * 4;
+                if (c < H) {
+                    float4 a = ld4(x + (size_t)j * H + c);
+                    if (GINE) {
+                        float4 ea = ld4(edge_emb + (size_t)e * H + c);
+                        a = make_float4(fmaxf(a.x + ea.x, 0.f), fmaxf(a.y + ea.y, 0.f), fmaxf(a.z + ea.z, 0.f), fmaxf(a.w + ea.w, 0.f));
+                    }
+                    acc[v] = f4fma(w, a, acc[v]);
+                }
+            }
+        }
+#pragma unroll
+        for (int v = 0; v < NV; ++v) {
+            int c = (v * LPR + lane) * 4;
+            if (c < H) st4(partial + (size_t)item * H + c, acc[v]);
+        }
+    }
+}
+
+// Long rows, backward: per-edge datt / dedge_emb are final; the dx contribution of the chunk goes to partial[item,:].
+template <int LPR, int NV, bool GINE>
+__global__ __launch_bounds__(AGG_BLOCK) void k_aggr_chunk_bwd(
+    const float* __restrict__ x, const float* __restrict__ att, const float* __restrict__ edge_emb, const float* __restrict__ dout,
+    const int32_t* __restrict__ rowptr, const int32_t* __restrict__ dstc, const int32_t* __restrict__ eid, int num_rows, int H,
+    float* __restrict__ datt, float* __restrict__ dedge, const int32_t* __restrict__ chunk_ptr, float* __restrict__ partial) {
+    constexpr int GPB = AGG_BLOCK / LPR;
+    const int lane = threadIdx.x % LPR;
+    const int total = chunk_ptr[num_rows];
+    for (int item = blockIdx.x * GPB + threadIdx.x / LPR; item < total; item += gridDim.x * GPB) {
+        int row, beg, end;
+        chunk_item(chunk_ptr, rowptr, num_rows, item, &row, &beg, &end);
+        float4 acc[NV], xj[NV];
+#pragma unroll
+        for (int v = 0; v < NV; ++v) {
+            int c = (v * LPR + lane) * 4;
+            acc[v] = f4zero();
+            xj[v] = c < H ? ld4(x + (size_t)row * H + c) : f4zero();
+        }
+        for (int k = beg; k < end; ++k) {
+            const int i = dstc[k], e = eid[k];
+            const float w = att ? att[e] : 1.f;
+            float dot = 0.f;
+#pragma unroll
+            for (int v = 0; v < NV; ++v) {
+                int c = (v * LPR + lane) * 4;
+                if (c < H) {
+                    float4 g = ld4(dout + (size_t)i * H + c);
+                    if (GINE) {
+                        float4 ea = ld4(edge_emb + (size_t)e * H + c);
+                        float4 pre = make_float4(xj[v].x + ea.x, xj[v].y + ea.y, xj[v].z + ea.z, xj[v].w + ea.w);
+                        float4 m = make_float4(fmaxf(pre.x, 0.f), fmaxf(pre.y, 0.f), fmaxf(pre.z, 0.f), fmaxf(pre.w, 0.f));
+                        dot += f4dot(m, g);
+                        g = make_float4(pre.x > 0.f ? g.x : 0.f, pre.y > 0.f ? g.y : 0.f, pre.z > 0.f ? g.z : 0.f, pre.w > 0.f ? g.w : 0.f);
+                        if (dedge) st4(dedge + (size_t)e * H + c, make_float4(w * g.x, w * g.y, w * g.z, w * g.w));
+                    } else {
+                        dot += f4dot(xj[v], g);
+                    }
+                    acc[v] = f4fma(w, g, acc[v]);
+                }
+            }
+            if (datt) {
+                dot = group_sum<LPR>(dot);
+                if (lane == 0) datt[e] = dot;
+            }
+        }
+#pragma unroll
+        for (int v = 0; v < NV; ++v) {
+            int c = (v * LPR + lane) * 4;
+            if (c < H) st4(partial + (size_t)item * H + c, acc[v]);
         }
     }
 }
@@ -254,29 +429,34 @@ static inline void span_grid(int64_t num_rows, int lpr, int* nblocks, int* rows_
     if (*rows_per_group < 1) *rows_per_group = 1;
 }
 
-}  // namespace gsat
 
-using namespace gsat;
+// upper bound on the number of long-row chunks of a CSR with E entries: every long row has > CH entries
+static inline int64_t max_chunks(int64_t E) { return 2 * (E / CH) + 1; }
 
-extern "C" {
-
-int gsat_aggr_sum_fwd(const float* x, const float* self_rows, const float* att, const float* edge_emb,
-                      const int32_t* rowptr, const int32_t* col, const int32_t* eid, int64_t N, int64_t H,
-                      float self_coef, float* out, void* stream_) {
-    hipStream_t stream = (hipStream_t)stream_;
+int aggr_sum_fwd_impl(hipStream_t stream, const float* x, const float* self_rows, const float* att, const float* edge_emb,
+                      const int32_t* rowptr, const int32_t* col, const int32_t* eid, int64_t N, int64_t E, int64_t H, float self_coef,
+                      float* out, const int32_t* chunk_ptr, float* partial) {
     GSAT_REQUIRE(N >= 0 && N < (1ll << 31), GSAT_ERR_ARG, "gsat_aggr_sum_fwd: bad N");
     if (N == 0) return GSAT_OK;
     RowGeom g;
     GSAT_REQUIRE(row_geom(H, &g), GSAT_ERR_UNSUPPORTED, "gsat_aggr_sum_fwd: H=%lld must be a multiple of 4 and <= 2048", (long long)H);
     GSAT_REQUIRE(x && rowptr && col && out, GSAT_ERR_ARG, "gsat_aggr_sum_fwd: null pointer");
     GSAT_REQUIRE((att == nullptr && edge_emb == nullptr) || eid, GSAT_ERR_ARG, "gsat_aggr_sum_fwd: eid required with att/edge_emb");
+    GSAT_REQUIRE(chunk_ptr == nullptr || partial != nullptr, GSAT_ERR_ARG, "gsat_aggr_sum_fwd: chunk_ptr needs a partial-sum workspace");
+    if (E <= CH) chunk_ptr = nullptr;                      // no row can be long
     if (!self_rows) self_rows = x;
     int nb, rpg;
     span_grid(N, g.lpr, &nb, &rpg);
+    const int cb = chunk_ptr ? (int)std::min<int64_t>(ceil_div(max_chunks(E), AGG_BLOCK / g.lpr), 256 * 16) : 0;
 #define CALL(L, V)                                                                                               \
     do {                                                                                                         \
-        if (edge_emb) k_aggr_sum_fwd<L, V, true><<<nb, AGG_BLOCK, 0, stream>>>(x, self_rows, att, edge_emb, rowptr, col, eid, (int)N, (int)H, self_coef, out, rpg); \
-        else k_aggr_sum_fwd<L, V, false><<<nb, AGG_BLOCK, 0, stream>>>(x, self_rows, att, edge_emb, rowptr, col, eid, (int)N, (int)H, self_coef, out, rpg);         \
+        if (edge_emb) {                                                                                          \
+            if (cb) k_aggr_chunk_fwd<L, V, true><<<cb, AGG_BLOCK, 0, stream>>>(x, att, edge_emb, rowptr, col, eid, (int)N, (int)H, chunk_ptr, partial); \
+            k_aggr_sum_fwd<L, V, true><<<nb, AGG_BLOCK, 0, stream>>>(x, self_rows, att, edge_emb, rowptr, col, eid, (int)N, (int)H, self_coef, out, rpg, chunk_ptr, partial); \
+        } else {                                                                                                 \
+            if (cb) k_aggr_chunk_fwd<L, V, false><<<cb, AGG_BLOCK, 0, stream>>>(x, att, edge_emb, rowptr, col, eid, (int)N, (int)H, chunk_ptr, partial); \
+            k_aggr_sum_fwd<L, V, false><<<nb, AGG_BLOCK, 0, stream>>>(x, self_rows, att, edge_emb, rowptr, col, eid, (int)N, (int)H, self_coef, out, rpg, chunk_ptr, partial); \
+        }                                                                                                        \
     } while (0)
     GSAT_ROW_DISPATCH(g, CALL);
 #undef CALL
@@ -284,21 +464,44 @@ int gsat_aggr_sum_fwd(const float* x, const float* self_rows, const float* att, 
     return GSAT_OK;
 }
 
+}  // namespace gsat
+
+using namespace gsat;
+
+extern "C" {
+
+size_t gsat_long_row_partial_floats(int64_t num_edges, int64_t H) { return (size_t)max_chunks(num_edges) * (size_t)H; }
+
+int gsat_aggr_sum_fwd(const float* x, const float* self_rows, const float* att, const float* edge_emb,
+                      const int32_t* rowptr, const int32_t* col, const int32_t* eid, int64_t N, int64_t E, int64_t H,
+                      float self_coef, float* out, const int32_t* chunk_ptr, float* partial, void* stream_) {
+    return aggr_sum_fwd_impl((hipStream_t)stream_, x, self_rows, att, edge_emb, rowptr, col, eid, N, E, H, self_coef, out, chunk_ptr, partial);
+}
+
 int gsat_aggr_sum_bwd(const float* x, const float* att, const float* edge_emb, const float* dout,
-                      const int32_t* rowptr_src, const int32_t* dst_sorted, const int32_t* eid_src, int64_t N,
-                      int64_t H, float self_coef, float* dx, float* datt, float* dedge_emb, void* stream_) {
+                      const int32_t* rowptr_src, const int32_t* dst_sorted, const int32_t* eid_src, int64_t N, int64_t E,
+                      int64_t H, float self_coef, float* dx, float* datt, float* dedge_emb, const int32_t* chunk_ptr,
+                      float* partial, void* stream_) {
     hipStream_t stream = (hipStream_t)stream_;
     GSAT_REQUIRE(N >= 0 && N < (1ll << 31), GSAT_ERR_ARG, "gsat_aggr_sum_bwd: bad N");
     if (N == 0) return GSAT_OK;
     RowGeom g;
     GSAT_REQUIRE(row_geom(H, &g), GSAT_ERR_UNSUPPORTED, "gsat_aggr_sum_bwd: H=%lld must be a multiple of 4 and <= 2048", (long long)H);
     GSAT_REQUIRE(x && dout && rowptr_src && dst_sorted && eid_src && dx, GSAT_ERR_ARG, "gsat_aggr_sum_bwd: null pointer");
+    GSAT_REQUIRE(chunk_ptr == nullptr || partial != nullptr, GSAT_ERR_ARG, "gsat_aggr_sum_bwd: chunk_ptr needs a partial-sum workspace");
+    if (E <= CH) chunk_ptr = nullptr;
     int nb, rpg;
     span_grid(N, g.lpr, &nb, &rpg);
+    const int cb = chunk_ptr ? (int)std::min<int64_t>(ceil_div(max_chunks(E), AGG_BLOCK / g.lpr), 256 * 16) : 0;
 #define CALL(L, V)                                                                                               \
     do {                                                                                                         \
-        if (edge_emb) k_aggr_sum_bwd<L, V, true><<<nb, AGG_BLOCK, 0, stream>>>(x, att, edge_emb, dout, rowptr_src, dst_sorted, eid_src, (int)N, (int)H, self_coef, dx, datt, dedge_emb, rpg); \
-        else k_aggr_sum_bwd<L, V, false><<<nb, AGG_BLOCK, 0, stream>>>(x, att, edge_emb, dout, rowptr_src, dst_sorted, eid_src, (int)N, (int)H, self_coef, dx, datt, dedge_emb, rpg);         \
+        if (edge_emb) {                                                                                          \
+            if (cb) k_aggr_chunk_bwd<L, V, true><<<cb, AGG_BLOCK, 0, stream>>>(x, att, edge_emb, dout, rowptr_src, dst_sorted, eid_src, (int)N, (int)H, datt, dedge_emb, chunk_ptr, partial); \
+            k_aggr_sum_bwd<L, V, true><<<nb, AGG_BLOCK, 0, stream>>>(x, att, edge_emb, dout, rowptr_src, dst_sorted, eid_src, (int)N, (int)H, self_coef, dx, datt, dedge_emb, rpg, chunk_ptr, partial); \
+        } else {                                                                                                 \
+            if (cb) k_aggr_chunk_bwd<L, V, false><<<cb, AGG_BLOCK, 0, stream>>>(x, att, edge_emb, dout, rowptr_src, dst_sorted, eid_src, (int)N, (int)H, datt, dedge_emb, chunk_ptr, partial); \
+            k_aggr_sum_bwd<L, V, false><<<nb, AGG_BLOCK, 0, stream>>>(x, att, edge_emb, dout, rowptr_src, dst_sorted, eid_src, (int)N, (int)H, self_coef, dx, datt, dedge_emb, rpg, chunk_ptr, partial); \
+        }                                                                                                        \
     } while (0)
     GSAT_ROW_DISPATCH(g, CALL);
 #undef CALL

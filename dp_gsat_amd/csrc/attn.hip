@@ -71,6 +71,61 @@ __device__ __forceinline__ float4 slot_reduce(float4 v, float4 (*sm)[SB_LANES], 
     return r;
 }
 
+// rows [beg,end) of the z-th of Z equal slices of segment g (Z > 1: few huge graphs, blockIdx.z = slice)
+__device__ __forceinline__ void seg_slice(const int32_t* __restrict__ seg_ptr, int g, int* beg, int* end, float* inv_n) {
+    const int b = seg_ptr[g], e = seg_ptr[g + 1];
+    *inv_n = 1.f / (float)max(e - b, 1);
+    const int Z = gridDim.z, z = blockIdx.z;
+    if (Z > 1) {
+        const int per = (e - b + Z - 1) / Z;
+        *beg = min(e, b + z * per);
+        *end = min(e, *beg + per);
+    } else {
+        *beg = b; *end = e;
+    }
+}
+
+// Z > 1 helpers for k_seg_stats: partial sums of h, then of (h - mean)^2, each followed by k_zcombine
+template <bool EDGE>
+__global__ __launch_bounds__(SB) void k_seg_partial(PreAct<EDGE> pre, const int32_t* __restrict__ seg_ptr, const int32_t* __restrict__ order,
+                                                    const float* __restrict__ mean /* null: plain sum */, float* __restrict__ part) {
+    __shared__ float4 sm[SB_SLOTS][SB_LANES];
+    const int g = blockIdx.x;
+    const int lane = threadIdx.x % SB_LANES, slot = threadIdx.x / SB_LANES;
+    const int c = (blockIdx.y * SB_LANES + lane) * 4;
+    const int C = pre.C;
+    const bool on = c < C;
+    int beg, end; float inv_n;
+    seg_slice(seg_ptr, g, &beg, &end, &inv_n);
+    float4 acc = f4zero();
+    if (on) {
+        const float4 mu = mean ? ld4(mean + (size_t)g * C + c) : f4zero();
+        for (int r = beg + slot; r < end; r += SB_SLOTS) {
+            float4 h = pre.load(order ? order[r] : r, c);
+            if (mean) {
+                float dx = h.x - mu.x, dy = h.y - mu.y, dz = h.z - mu.z, dw = h.w - mu.w;
+                acc.x = fmaf(dx, dx, acc.x); acc.y = fmaf(dy, dy, acc.y); acc.z = fmaf(dz, dz, acc.z); acc.w = fmaf(dw, dw, acc.w);
+            } else {
+                acc.x += h.x; acc.y += h.y; acc.z += h.z; acc.w += h.w;
+            }
+        }
+    }
+    float4 tot = slot_reduce(acc, sm, slot, lane);
+    if (slot == 0 && on) st4(part + ((size_t)g * gridDim.z + blockIdx.z) * C + c, tot);
+}
+
+// out[g,c] = f(sum_z part[g,z,c]):  mode 0 raw sum, 1 sum/n, 2 1/sqrt(sum/n + eps)
+__global__ void k_zcombine(const float* __restrict__ part, const int32_t* __restrict__ seg_ptr, int G, int Z, int C, int mode,
+                           float* __restrict__ out) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (int64_t)G * C) return;
+    const int g = (int)(i / C), c = (int)(i % C);
+    float acc = 0.f;
+    for (int z = 0; z < Z; ++z) acc += part[((size_t)g * Z + z) * C + c];
+    const float inv_n = 1.f / (float)max(seg_ptr[g + 1] - seg_ptr[g], 1);
+    out[i] = mode == 0 ? acc : mode == 1 ? acc * inv_n : 1.f / sqrtf(acc * inv_n + IN_EPS);
+}
+
 // ------------------------------------------------------------------------------------------------
 // per-graph, per-channel InstanceNorm statistics: grid (G, ceil(C/64)); two passes over the segment
 // (mean, then variance of the centred values -- the reference's order), second pass is L2-hot.
@@ -195,8 +250,10 @@ __global__ __launch_bounds__(SB) void k_head_bwd_stats(const float* __restrict__
     const int lane = threadIdx.x % SB_LANES, slot = threadIdx.x / SB_LANES;
     const int c = (blockIdx.y * SB_LANES + lane) * 4;
     const bool on = c < C;
-    const int beg = seg_ptr[g], end = seg_ptr[g + 1];
-    const float inv_n = 1.f / (float)max(end - beg, 1);
+    int beg, end; float inv_n;
+    seg_slice(seg_ptr, g, &beg, &end, &inv_n);
+    if (gridDim.z > 1) inv_n = 1.f;                         // raw partial sums, scaled by k_zcombine
+    const size_t orow = gridDim.z > 1 ? (size_t)g * gridDim.z + blockIdx.z : (size_t)g;
     const float sc = (training && p > 0.f) ? 1.f / (1.f - p) : 1.f;
     PreAct<false> pre{h2, nullptr, b2, nullptr, nullptr, C};
     float4 a1 = f4zero(), a2 = f4zero(), a3 = f4zero();
@@ -220,9 +277,9 @@ __global__ __launch_bounds__(SB) void k_head_bwd_stats(const float* __restrict__
     float4 t2 = slot_reduce(a2, sm, slot, lane);
     float4 t3 = slot_reduce(a3, sm, slot, lane);
     if (slot == 0 && on) {
-        st4(S1 + (size_t)g * C + c, make_float4(t1.x * inv_n, t1.y * inv_n, t1.z * inv_n, t1.w * inv_n));
-        st4(S2 + (size_t)g * C + c, make_float4(t2.x * inv_n, t2.y * inv_n, t2.z * inv_n, t2.w * inv_n));
-        st4(dw3p + (size_t)g * C + c, t3);
+        st4(S1 + orow * C + c, make_float4(t1.x * inv_n, t1.y * inv_n, t1.z * inv_n, t1.w * inv_n));
+        st4(S2 + orow * C + c, make_float4(t2.x * inv_n, t2.y * inv_n, t2.z * inv_n, t2.w * inv_n));
+        st4(dw3p + orow * C + c, t3);
     }
 }
 
@@ -259,8 +316,10 @@ __global__ __launch_bounds__(SB) void k_l1_bwd_stats(const float* __restrict__ d
     const int lane = threadIdx.x % SB_LANES, slot = threadIdx.x / SB_LANES;
     const int c = (blockIdx.y * SB_LANES + lane) * 4;
     const bool on = c < C;
-    const int beg = seg_ptr[g], end = seg_ptr[g + 1];
-    const float inv_n = 1.f / (float)max(end - beg, 1);
+    int beg, end; float inv_n;
+    seg_slice(seg_ptr, g, &beg, &end, &inv_n);
+    if (gridDim.z > 1) inv_n = 1.f;                         // raw partial sums, scaled by k_zcombine
+    const size_t orow = gridDim.z > 1 ? (size_t)g * gridDim.z + blockIdx.z : (size_t)g;
     const float inv_sc = 1.f / sc;
     float4 s1 = f4zero(), s2 = f4zero();
     if (on)
@@ -275,8 +334,8 @@ __global__ __launch_bounds__(SB) void k_l1_bwd_stats(const float* __restrict__ d
     float4 t1 = slot_reduce(s1, sm, slot, lane);
     float4 t2 = slot_reduce(s2, sm, slot, lane);
     if (slot == 0 && on) {
-        st4(S1 + (size_t)g * C + c, make_float4(t1.x * inv_n, t1.y * inv_n, t1.z * inv_n, t1.w * inv_n));
-        st4(S2 + (size_t)g * C + c, make_float4(t2.x * inv_n, t2.y * inv_n, t2.z * inv_n, t2.w * inv_n));
+        st4(S1 + orow * C + c, make_float4(t1.x * inv_n, t1.y * inv_n, t1.z * inv_n, t1.w * inv_n));
+        st4(S2 + orow * C + c, make_float4(t2.x * inv_n, t2.y * inv_n, t2.z * inv_n, t2.w * inv_n));
     }
 }
 
@@ -309,8 +368,10 @@ __global__ __launch_bounds__(SB) void k_in_bwd_stats(const float* __restrict__ y
     const int lane = threadIdx.x % SB_LANES, slot = threadIdx.x / SB_LANES;
     const int c = (blockIdx.y * SB_LANES + lane) * 4;
     const bool on = c < C;
-    const int beg = seg_ptr[g], end = seg_ptr[g + 1];
-    const float inv_n = 1.f / (float)max(end - beg, 1);
+    int beg, end; float inv_n;
+    seg_slice(seg_ptr, g, &beg, &end, &inv_n);
+    if (gridDim.z > 1) inv_n = 1.f;                         // raw partial sums, scaled by k_zcombine
+    const size_t orow = gridDim.z > 1 ? (size_t)g * gridDim.z + blockIdx.z : (size_t)g;
     float4 s1 = f4zero(), s2 = f4zero();
     if (on)
         for (int r = beg + slot; r < end; r += SB_SLOTS) {
@@ -322,8 +383,8 @@ __global__ __launch_bounds__(SB) void k_in_bwd_stats(const float* __restrict__ y
     float4 t1 = slot_reduce(s1, sm, slot, lane);
     float4 t2 = slot_reduce(s2, sm, slot, lane);
     if (slot == 0 && on) {
-        st4(S1 + (size_t)g * C + c, make_float4(t1.x * inv_n, t1.y * inv_n, t1.z * inv_n, t1.w * inv_n));
-        st4(S2 + (size_t)g * C + c, make_float4(t2.x * inv_n, t2.y * inv_n, t2.z * inv_n, t2.w * inv_n));
+        st4(S1 + orow * C + c, make_float4(t1.x * inv_n, t1.y * inv_n, t1.z * inv_n, t1.w * inv_n));
+        st4(S2 + orow * C + c, make_float4(t2.x * inv_n, t2.y * inv_n, t2.z * inv_n, t2.w * inv_n));
     }
 }
 
@@ -372,24 +433,6 @@ __global__ __launch_bounds__(SB) void k_colsum(const float* __restrict__ x, int6
     }
 }
 
-// Segment sum of dh1 rows through a CSR of edge ids: out[n,:] = sum_{k in row n} dh1[eid[k],:]
-__global__ __launch_bounds__(256) void k_rows_by_eid(const float* __restrict__ rows, const int32_t* __restrict__ rowptr,
-                                                     const int32_t* __restrict__ eid, int N, int C, float* __restrict__ out) {
-    // 64 lanes (one wave) per node row, float4 per lane, loop over column chunks
-    const int lane = threadIdx.x & 63;
-    for (int n = blockIdx.x * 4 + (threadIdx.x >> 6); n < N; n += gridDim.x * 4) {
-        const int beg = rowptr[n], end = rowptr[n + 1];
-        for (int c = lane * 4; c < C; c += 256) {
-            float4 acc = f4zero();
-            for (int k = beg; k < end; ++k) {
-                float4 v = ld4(rows + (size_t)eid[k] * C + c);
-                acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
-            }
-            st4(out + (size_t)n * C + c, acc);
-        }
-    }
-}
-
 __global__ void k_philox_mask(uint64_t seed, int layer, int64_t M, int C, float p, float* __restrict__ keep) {
     const int C4 = C >> 2;
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < M * C4; i += (int64_t)gridDim.x * blockDim.x) {
@@ -416,6 +459,33 @@ static int colsum(hipStream_t stream, const float* x, int64_t R, int C, float* o
         RB = ceil_div(R, rpb);
         k_colsum<<<dim3(ctiles, (unsigned)RB), SB, 0, stream>>>(x, R, C, rpb, scratch);
         k_colsum<<<dim3(ctiles, 1), SB, 0, stream>>>(scratch, RB, C, RB, out);
+    }
+    GSAT_LAUNCH_CHECK();
+    return GSAT_OK;
+}
+
+// number of row slices per segment for the segmented statistics: 1 for batches of small graphs, up to 64 when a
+// graph has tens of thousands of rows (C5); must agree between the workspace queries and the launches.
+static inline int seg_slices(int64_t rows, int64_t G) {
+    const int64_t avg = rows / std::max<int64_t>(G, 1);
+    return (int)std::max<int64_t>(1, std::min<int64_t>(64, ceil_div(avg, 4096)));
+}
+
+template <bool EDGE>
+static int launch_seg_stats(hipStream_t stream, PreAct<EDGE> pre, const int32_t* seg_ptr, const int32_t* order, int64_t G, int Z,
+                            float* mean, float* rstd, float* part) {
+    if (G <= 0) return GSAT_OK;
+    const int C = pre.C;
+    const dim3 grid((unsigned)G, (unsigned)ceil_div(C, 64), (unsigned)Z);
+    if (Z == 1) {
+        k_seg_stats<EDGE><<<grid, SB, 0, stream>>>(pre, seg_ptr, order, mean, rstd);
+    } else {
+        GSAT_REQUIRE(part, GSAT_ERR_WORKSPACE, "segmented statistics need a workspace for sliced segments");
+        const unsigned cb = (unsigned)ceil_div(G * C, 256);
+        k_seg_partial<EDGE><<<grid, SB, 0, stream>>>(pre, seg_ptr, order, nullptr, part);
+        k_zcombine<<<cb, 256, 0, stream>>>(part, seg_ptr, (int)G, Z, C, 1, mean);
+        k_seg_partial<EDGE><<<grid, SB, 0, stream>>>(pre, seg_ptr, order, mean, part);
+        k_zcombine<<<cb, 256, 0, stream>>>(part, seg_ptr, (int)G, Z, C, 2, rstd);
     }
     GSAT_LAUNCH_CHECK();
     return GSAT_OK;
@@ -465,14 +535,20 @@ int gsat_attn_fwd(const gsat_attn_args* a, void* stream_) {
     } else {
         if ((rc = gemm_rm(stream, false, true, N, C1, H, a->emb, H, a->W1, H, 0.f, a->P, C1))) return rc;
     }
-    const dim3 g1((unsigned)G, (unsigned)ceil_div(C1, 64)), g2((unsigned)G, (unsigned)ceil_div(C2, 64));
+    const int Z = seg_slices(M, G);
+    float* part = nullptr;
+    if (Z > 1) {
+        const size_t need = (size_t)G * Z * std::max(C1, C2) * sizeof(float);
+        GSAT_REQUIRE(a->fwd_workspace && a->fwd_workspace_bytes >= need, GSAT_ERR_WORKSPACE, "gsat_attn_fwd: workspace %zu < %zu", a->fwd_workspace_bytes, need);
+        part = static_cast<float*>(a->fwd_workspace);
+    }
     if (a->edge_mode) {
         PreAct<true> pre{a->P, a->Q, a->b1, a->src, a->dst, C1};
-        if (G > 0) k_seg_stats<true><<<g1, SB, 0, stream>>>(pre, a->seg_ptr, a->seg_order, mean1, rstd1);
+        if ((rc = launch_seg_stats<true>(stream, pre, a->seg_ptr, a->seg_order, G, Z, mean1, rstd1, part))) return rc;
         k_norm_apply<true, true><<<ew_blocks(M * (C1 / 4)), 256, 0, stream>>>(pre, a->row_seg, mean1, rstd1, a->mask1, a->seed, 1, a->p_drop, a->training, M, a->a1);
     } else {
         PreAct<false> pre{a->P, nullptr, a->b1, nullptr, nullptr, C1};
-        if (G > 0) k_seg_stats<false><<<g1, SB, 0, stream>>>(pre, a->seg_ptr, a->seg_order, mean1, rstd1);
+        if ((rc = launch_seg_stats<false>(stream, pre, a->seg_ptr, a->seg_order, G, Z, mean1, rstd1, part))) return rc;
         k_norm_apply<false, true><<<ew_blocks(M * (C1 / 4)), 256, 0, stream>>>(pre, a->row_seg, mean1, rstd1, a->mask1, a->seed, 1, a->p_drop, a->training, M, a->a1);
     }
     GSAT_LAUNCH_CHECK();
@@ -480,8 +556,7 @@ int gsat_attn_fwd(const gsat_attn_args* a, void* stream_) {
     if ((rc = gemm_rm(stream, false, true, M, C2, C1, a->a1, C1, a->W2, C1, 0.f, a->h2, C2))) return rc;
     {
         PreAct<false> pre{a->h2, nullptr, a->b2, nullptr, nullptr, C2};
-        if (G > 0) k_seg_stats<false><<<g2, SB, 0, stream>>>(pre, a->seg_ptr, a->seg_order, mean2, rstd2);
-        GSAT_LAUNCH_CHECK();
+        if ((rc = launch_seg_stats<false>(stream, pre, a->seg_ptr, a->seg_order, G, Z, mean2, rstd2, part))) return rc;
     }
     // ---- head + sampler ---------------------------------------------------------------------
     const int q = C2 / 4;
@@ -492,6 +567,12 @@ int gsat_attn_fwd(const gsat_attn_args* a, void* stream_) {
 #undef HEAD
     GSAT_LAUNCH_CHECK();
     return GSAT_OK;
+}
+
+size_t gsat_attn_fwd_workspace_bytes(const gsat_attn_args* a) {
+    if (!a) return 0;
+    const int Z = seg_slices(a->M, a->G);
+    return Z > 1 ? (size_t)a->G * Z * std::max(a->C1, a->C2) * sizeof(float) : 0;
 }
 
 size_t gsat_attn_bwd_workspace_bytes(const gsat_attn_args* a) {
@@ -505,7 +586,8 @@ size_t gsat_attn_bwd_workspace_bytes(const gsat_attn_args* a) {
     b += 2 * align_up(G * C1 * 4, 256);        // S1', S2'
     b += 3 * align_up(G * C2 * 4, 256);        // S1, S2, dw3 partial
     b += align_up(256 * cmax * 4, 256);        // column-sum scratch
-    if (a->edge_mode) b += 2 * align_up(N * C1 * 4, 256);   // dP, dQ
+    { const size_t Z = seg_slices(a->M, a->G); if (Z > 1) b += 3 * align_up(G * Z * cmax * 4, 256); }   // sliced-segment partials
+    if (a->edge_mode) b += 2 * align_up(N * C1 * 4, 256) + align_up(gsat_long_row_partial_floats(a->M, a->C1) * 4, 256);   // dP, dQ, hub partials
     b += align_up(attn_gemm_ws_floats(a) * 4, 256);          // split-K slabs of the weight-gradient GEMMs
     return b + 1024;
 }
@@ -541,8 +623,19 @@ int gsat_attn_bwd(const gsat_attn_args* a, const gsat_attn_grads* gr, void* stre
     float* S2 = ar.take<float>((size_t)G * C2);
     float* dw3p = ar.take<float>((size_t)G * C2);
     float* scratch = ar.take<float>((size_t)256 * std::max(C1, C2));
+    const int Z = seg_slices(M, G);
+    float *zp1 = nullptr, *zp2 = nullptr, *zp3 = nullptr;
+    if (Z > 1) {
+        const size_t n = (size_t)G * Z * std::max(C1, C2);
+        zp1 = ar.take<float>(n); zp2 = ar.take<float>(n); zp3 = ar.take<float>(n);
+    }
     float *dP = nullptr, *dQ = nullptr;
-    if (a->edge_mode) { dP = ar.take<float>((size_t)N * C1); dQ = ar.take<float>((size_t)N * C1); }
+    float* lpart = nullptr;
+    if (a->edge_mode) {
+        dP = ar.take<float>((size_t)N * C1);
+        dQ = ar.take<float>((size_t)N * C1);
+        lpart = ar.take<float>(gsat_long_row_partial_floats(M, C1));
+    }
     GemmWs gws{nullptr, attn_gemm_ws_floats(a)};
     gws.ptr = ar.take<float>(gws.floats);
     GSAT_REQUIRE(ar.ok(), GSAT_ERR_WORKSPACE, "gsat_attn_bwd: workspace %zu < %zu", gr->workspace_bytes, ar.off);
@@ -556,9 +649,15 @@ int gsat_attn_bwd(const gsat_attn_args* a, const gsat_attn_grads* gr, void* stre
     GSAT_LAUNCH_CHECK();
     if ((rc = colsum(stream, dz, M, 1, gr->db3, scratch))) return rc;
     // ---- through the head and the second InstanceNorm ------------------------------------------
-    const dim3 g2((unsigned)G, (unsigned)ceil_div(C2, 64)), g1((unsigned)G, (unsigned)ceil_div(C1, 64));
+    const dim3 g2((unsigned)G, (unsigned)ceil_div(C2, 64), (unsigned)Z), g1((unsigned)G, (unsigned)ceil_div(C1, 64), (unsigned)Z);
     k_head_bwd_stats<<<g2, SB, 0, stream>>>(a->h2, a->b2, a->seg_ptr, a->seg_order, mean2, rstd2, a->mask2, a->seed, a->p_drop,
-                                            a->training, a->W3, dz, C2, S1, S2, dw3p);
+                                            a->training, a->W3, dz, C2, Z > 1 ? zp1 : S1, Z > 1 ? zp2 : S2, Z > 1 ? zp3 : dw3p);
+    if (Z > 1) {
+        const unsigned cb = (unsigned)ceil_div(G * C2, 256);
+        k_zcombine<<<cb, 256, 0, stream>>>(zp1, a->seg_ptr, (int)G, Z, C2, 1, S1);
+        k_zcombine<<<cb, 256, 0, stream>>>(zp2, a->seg_ptr, (int)G, Z, C2, 1, S2);
+        k_zcombine<<<cb, 256, 0, stream>>>(zp3, a->seg_ptr, (int)G, Z, C2, 0, dw3p);
+    }
     GSAT_LAUNCH_CHECK();
     if ((rc = colsum(stream, dw3p, G, C2, gr->dW3, scratch))) return rc;
     k_dh2<<<ew_blocks(M * (C2 / 4)), 256, 0, stream>>>(a->h2, a->b2, a->row_seg, mean2, rstd2, a->mask2, a->seed, a->p_drop, a->training,
@@ -572,16 +671,22 @@ int gsat_attn_bwd(const gsat_attn_args* a, const gsat_attn_grads* gr, void* stre
     if ((rc = gemm_rm(stream, true, false, C2, C1, M, dh2, C2, a->a1, C1, 0.f, gr->dW2, C1, gws))) return rc;
     if ((rc = gemm_rm(stream, false, false, M, C1, C2, dh2, C2, a->W2, C1, 0.f, da1, C1))) return rc;
     // ---- through ReLU/dropout and the first InstanceNorm ---------------------------------------
-    k_l1_bwd_stats<<<g1, SB, 0, stream>>>(da1, a->a1, a->seg_ptr, a->seg_order, sc, C1, S1p, S2p);
+    k_l1_bwd_stats<<<g1, SB, 0, stream>>>(da1, a->a1, a->seg_ptr, a->seg_order, sc, C1, Z > 1 ? zp1 : S1p, Z > 1 ? zp2 : S2p);
+    if (Z > 1) {
+        const unsigned cb = (unsigned)ceil_div(G * C1, 256);
+        k_zcombine<<<cb, 256, 0, stream>>>(zp1, a->seg_ptr, (int)G, Z, C1, 1, S1p);
+        k_zcombine<<<cb, 256, 0, stream>>>(zp2, a->seg_ptr, (int)G, Z, C1, 1, S2p);
+    }
     GSAT_LAUNCH_CHECK();
     if (a->edge_mode) {
         PreAct<true> pre{a->P, a->Q, a->b1, a->src, a->dst, C1};
         k_dh1<true><<<ew_blocks(M * (C1 / 4)), 256, 0, stream>>>(pre, a->row_seg, mean1, rstd1, a->a1, sc, S1p, S2p, M, da1);
         GSAT_LAUNCH_CHECK();
-        const int nbn = (int)std::min<int64_t>(ceil_div(N, 4), 256 * 16);
-        k_rows_by_eid<<<nbn, 256, 0, stream>>>(da1, gr->rowptr_src, gr->eid_by_src, (int)N, C1, dP);
-        k_rows_by_eid<<<nbn, 256, 0, stream>>>(da1, gr->rowptr_dst, gr->eid_by_dst, (int)N, C1, dQ);
-        GSAT_LAUNCH_CHECK();
+        // dP[n,:] = sum over out-edges of n of dh1[e,:], dQ[n,:] = sum over in-edges (gather-sum, hub rows chunked)
+        if ((rc = aggr_sum_fwd_impl(stream, da1, nullptr, nullptr, nullptr, gr->rowptr_src, gr->eid_by_src, nullptr, N, M, C1, 0.f, dP,
+                                    gr->chunk_ptr_src, lpart))) return rc;
+        if ((rc = aggr_sum_fwd_impl(stream, da1, nullptr, nullptr, nullptr, gr->rowptr_dst, gr->eid_by_dst, nullptr, N, M, C1, 0.f, dQ,
+                                    gr->chunk_ptr_dst, lpart))) return rc;
         // demb = dP W1a + dQ W1b ; dW1[:, :H] = dP^T emb ; dW1[:, H:] = dQ^T emb
         if ((rc = gemm_rm(stream, false, false, N, H, C1, dP, C1, a->W1, 2 * H, 0.f, gr->demb, H))) return rc;
         if ((rc = gemm_rm(stream, false, false, N, H, C1, dQ, C1, a->W1 + H, 2 * H, 1.f, gr->demb, H))) return rc;
@@ -606,7 +711,7 @@ int gsat_instance_norm_fwd(const float* x, const int32_t* seg_ptr, const int32_t
     float* mean = stats;
     float* rstd = stats + (size_t)G * C;
     PreAct<false> pre{x, nullptr, nullptr, nullptr, nullptr, (int)C};
-    k_seg_stats<false><<<dim3((unsigned)G, (unsigned)ceil_div(C, 64)), SB, 0, stream>>>(pre, seg_ptr, seg_order, mean, rstd);
+    k_seg_stats<false><<<dim3((unsigned)G, (unsigned)ceil_div(C, 64), 1), SB, 0, stream>>>(pre, seg_ptr, seg_order, mean, rstd);
     k_norm_apply<false, false><<<ew_blocks(M * (C / 4)), 256, 0, stream>>>(pre, row_seg, mean, rstd, nullptr, 0, 0, 0.f, 0, M, y);
     GSAT_LAUNCH_CHECK();
     return GSAT_OK;
@@ -620,7 +725,7 @@ int gsat_instance_norm_bwd(const float* y, const float* dy, const float* stats, 
     GSAT_REQUIRE(y && dy && stats && seg_ptr && row_seg && dx && workspace, GSAT_ERR_ARG, "gsat_instance_norm_bwd: null pointer");
     float* S1 = workspace;
     float* S2 = workspace + (size_t)G * C;
-    k_in_bwd_stats<<<dim3((unsigned)G, (unsigned)ceil_div(C, 64)), SB, 0, stream>>>(y, dy, seg_ptr, seg_order, (int)C, S1, S2);
+    k_in_bwd_stats<<<dim3((unsigned)G, (unsigned)ceil_div(C, 64), 1), SB, 0, stream>>>(y, dy, seg_ptr, seg_order, (int)C, S1, S2);
     k_in_bwd_apply<<<ew_blocks(M * (C / 4)), 256, 0, stream>>>(y, dy, row_seg, stats + (size_t)G * C, S1, S2, M, (int)C, dx);
     GSAT_LAUNCH_CHECK();
     return GSAT_OK;

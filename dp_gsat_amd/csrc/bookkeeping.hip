@@ -86,6 +86,24 @@ __global__ void k_gather_i64(const int64_t* __restrict__ table, const int64_t* _
     if (i < n) out[i] = table[index[i]];
 }
 
+struct ChunkCount {      // number of GSAT_LONG_ROW_EDGES-sized chunks of row r (0 for short rows and for r == num_rows)
+    const int32_t* rowptr;
+    int num_rows;
+    __host__ __device__ int operator()(int r) const {
+        if (r >= num_rows) return 0;
+        const int deg = rowptr[r + 1] - rowptr[r];
+        return deg > GSAT_LONG_ROW_EDGES ? (deg + GSAT_LONG_ROW_EDGES - 1) / GSAT_LONG_ROW_EDGES : 0;
+    }
+};
+
+static size_t chunk_scan_temp_bytes(int64_t n) {
+    size_t tb = 0;
+    auto in = rocprim::make_transform_iterator(rocprim::make_counting_iterator<int>(0), ChunkCount{nullptr, 0});
+    int32_t* out = nullptr;
+    (void)rocprim::exclusive_scan(nullptr, tb, in, out, 0, (size_t)(n + 1), rocprim::plus<int>(), (hipStream_t)0);
+    return align_up(tb, 256) + 256;
+}
+
 template <class K>
 static size_t sort_temp_bytes(int64_t n) {
     size_t tb = 0;
@@ -180,6 +198,18 @@ int gsat_reverse_edge_perm(const int64_t* edge_index, int64_t E, int64_t N, int3
     GSAT_LAUNCH_CHECK();
     k_finish_flags<<<1, 1, 0, stream>>>(flags);
     GSAT_LAUNCH_CHECK();
+    return GSAT_OK;
+}
+
+size_t gsat_row_chunks_workspace_bytes(int64_t num_rows) { return chunk_scan_temp_bytes(num_rows); }
+
+int gsat_row_chunks(const int32_t* rowptr, int64_t num_rows, int32_t* chunk_ptr, void* workspace, size_t ws_bytes, void* stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    GSAT_REQUIRE(num_rows >= 0 && num_rows < (1ll << 31) - 1 && rowptr && chunk_ptr, GSAT_ERR_ARG, "gsat_row_chunks: bad argument");
+    size_t tb = chunk_scan_temp_bytes(num_rows);
+    GSAT_REQUIRE(workspace && ws_bytes >= tb, GSAT_ERR_WORKSPACE, "gsat_row_chunks: workspace %zu < %zu", ws_bytes, tb);
+    auto in = rocprim::make_transform_iterator(rocprim::make_counting_iterator<int>(0), ChunkCount{rowptr, (int)num_rows});
+    GSAT_CHECK_HIP(rocprim::exclusive_scan(workspace, tb, in, chunk_ptr, 0, (size_t)(num_rows + 1), rocprim::plus<int>(), stream));
     return GSAT_OK;
 }
 

@@ -56,6 +56,11 @@ int gemm_f32(hipStream_t stream, bool a_t, bool b_t, int64_t M, int64_t N, int64
              int64_t ldb, float* C, int64_t ldc, const float* bias, bool accumulate, float* ws, size_t ws_floats);
 size_t gemm_workspace_floats(int64_t M, int64_t N, int64_t K, bool reduce_rows);
 
+// ---- gather-sum over a CSR (aggregate.hip), reused by the extractor backward -------------------------
+int aggr_sum_fwd_impl(hipStream_t stream, const float* x, const float* self_rows, const float* att, const float* edge_emb,
+                      const int32_t* rowptr, const int32_t* col, const int32_t* eid, int64_t N, int64_t E, int64_t H, float self_coef,
+                      float* out, const int32_t* chunk_ptr, float* partial);
+
 // ---- device helpers -------------------------------------------------------------------------
 #ifdef __HIPCC__
 constexpr int WAVE = 64;

@@ -51,6 +51,14 @@ class BatchIndex:
         self.eid_by_src = _i32(E, dev)
         call("gsat_build_csr", ptr(src), ptr(dst), E, N, ptr(self.rowptr_src), ptr(self.dst_by_src),
              ptr(self.eid_by_src), ptr(self._err), ptr(ws), ws_bytes, stream())
+        # long-row (hub) chunk lists of both CSRs: empty for molecule-like graphs, built without a host sync
+        cws_bytes = max(call_size("gsat_row_chunks_workspace_bytes", N), 256)
+        cws = torch.empty(cws_bytes, dtype=torch.uint8, device=dev)
+        self.chunk_ptr_dst = torch.empty(N + 1, dtype=torch.int32, device=dev)
+        self.chunk_ptr_src = torch.empty(N + 1, dtype=torch.int32, device=dev)
+        call("gsat_row_chunks", ptr(self.rowptr_dst), N, ptr(self.chunk_ptr_dst), ptr(cws), cws_bytes, stream())
+        call("gsat_row_chunks", ptr(self.rowptr_src), N, ptr(self.chunk_ptr_src), ptr(cws), cws_bytes, stream())
+        self._partials = {}
         # int32 copies of the two edge_index rows (original edge order) for the per-edge kernels
         self.src32 = _i32(E, dev)
         self.dst32 = _i32(E, dev)
@@ -61,6 +69,16 @@ class BatchIndex:
         self._undirected = None
         self._slot_dst_of_srcslot = None
         self._graphs = {}
+
+    def partial(self, H: int) -> torch.Tensor:
+        """Scratch for the long-row partial sums of width H (upper bound, no host sync); reused across calls
+        on the same stream."""
+        buf = self._partials.get(H)
+        if buf is None:
+            n = max(call_size("gsat_long_row_partial_floats", self.E, H), 4)
+            buf = torch.empty(n, dtype=torch.float32, device=self.device)
+            self._partials[H] = buf
+        return buf
 
     # -- validation (one host sync, deferred until something needs a host-side decision) --------
     def check(self):

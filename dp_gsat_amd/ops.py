@@ -48,7 +48,8 @@ class MaskedSumAggregate(torch.autograd.Function):
                              "'edge_dim' attribute of 'GINEConv'")     # src/models/conv_layers.py:54-57
         out = torch.empty_like(x)
         call("gsat_aggr_sum_fwd", ptr(x), None, ptr(attf), ptr(edge_emb), ptr(index.rowptr_dst),
-             ptr(index.src_by_dst), ptr(index.eid_by_dst), N, H, float(self_coef), ptr(out), stream())
+             ptr(index.src_by_dst), ptr(index.eid_by_dst), N, index.E, H, float(self_coef), ptr(out),
+             ptr(index.chunk_ptr_dst), ptr(index.partial(H)), stream())
         ctx.save_for_backward(x, attf, edge_emb)
         ctx.index, ctx.self_coef = index, float(self_coef)
         ctx.att_shape = None if att is None else att.shape
@@ -66,7 +67,8 @@ class MaskedSumAggregate(torch.autograd.Function):
         datt = torch.empty(index.E, dtype=torch.float32, device=x.device) if need_att else None
         dee = torch.empty_like(edge_emb) if need_ee else None
         call("gsat_aggr_sum_bwd", ptr(x), ptr(attf), ptr(edge_emb), ptr(dout), ptr(index.rowptr_src),
-             ptr(index.dst_by_src), ptr(index.eid_by_src), N, H, ctx.self_coef, ptr(dx), ptr(datt), ptr(dee), stream())
+             ptr(index.dst_by_src), ptr(index.eid_by_src), N, index.E, H, ctx.self_coef, ptr(dx), ptr(datt), ptr(dee),
+             ptr(index.chunk_ptr_src), ptr(index.partial(H)), stream())
         return dx, (datt.view(ctx.att_shape) if need_att else None), dee, None, None
 
 
@@ -159,7 +161,8 @@ class PnaAggregate(torch.autograd.Function):
         # second pass: sum the per-edge gradient rows of every source node through the inverted index
         dx = torch.empty_like(x)
         call("gsat_aggr_sum_fwd", ptr(dmsg), ptr(dx_self), None, None, ptr(index.rowptr_src),
-             ptr(index.slot_dst_of_srcslot), None, N, H, 1.0, ptr(dx), stream())
+             ptr(index.slot_dst_of_srcslot), None, N, index.E, H, 1.0, ptr(dx),
+             ptr(index.chunk_ptr_src), ptr(index.partial(H)), stream())
         return dx, (datt.view(ctx.att_shape) if need_att else None), dee, None, None, None, None, None
 
 
@@ -231,6 +234,11 @@ class ExtractorAttention(torch.autograd.Function):
         att = torch.empty(M, 1, dtype=f32, device=dev)
         bufs = (P, Q, a1, h2, stats, logits, att)
         args = _attn_args(emb, params, index, segments, edge_mode, training, p, seed, mask1, mask2, u, bufs)
+        from ._lib import load
+        fws_bytes = int(load().gsat_attn_fwd_workspace_bytes(ctypes.byref(args)))
+        if fws_bytes:
+            fws = torch.empty(fws_bytes, dtype=torch.uint8, device=dev)
+            args.fwd_workspace, args.fwd_workspace_bytes = ptr(fws), fws_bytes
         call("gsat_attn_fwd", ctypes.byref(args), stream())
         ctx.save_for_backward(emb, *params, P, Q if Q is not None else emb.new_empty(0), a1, h2, stats, att,
                               mask1 if mask1 is not None else emb.new_empty(0),
@@ -258,6 +266,7 @@ class ExtractorAttention(torch.autograd.Function):
         if edge_mode:
             g.rowptr_src, g.eid_by_src = ptr(index.rowptr_src), ptr(index.eid_by_src)
             g.rowptr_dst, g.eid_by_dst = ptr(index.rowptr_dst), ptr(index.eid_by_dst)
+            g.chunk_ptr_src, g.chunk_ptr_dst = ptr(index.chunk_ptr_src), ptr(index.chunk_ptr_dst)
         demb = torch.empty_like(emb)
         grads = [torch.empty_like(t) for t in params]
         g.demb = ptr(demb)

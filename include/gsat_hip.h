@@ -86,18 +86,34 @@ int gsat_gather_i64(const int64_t* table, const int64_t* index, int64_t n, int64
 /* ============================ masked message passing: sum (GIN / GINE) ====================== */
 
 /*
+ * Rows with more than GSAT_LONG_ROW_EDGES entries (power-law hubs) are split into chunks of that many
+ * consecutive CSR slots: chunk sums go to a partial workspace and are added per row in chunk order, so the
+ * result stays atomics-free and bitwise reproducible.  chunk_ptr[r]..chunk_ptr[r+1] = chunk ids of row r
+ * (empty for short rows); built once per CSR by gsat_row_chunks.  Pass chunk_ptr = NULL to process every
+ * row whole.
+ */
+#define GSAT_LONG_ROW_EDGES 256
+size_t gsat_row_chunks_workspace_bytes(int64_t num_rows);
+int gsat_row_chunks(const int32_t* rowptr, int64_t num_rows, int32_t* chunk_ptr /* [num_rows+1] */,
+                    void* workspace, size_t workspace_bytes, void* stream);
+/* floats needed for the partial-sum workspace of a CSR with num_edges entries and row width H */
+size_t gsat_long_row_partial_floats(int64_t num_edges, int64_t H);
+
+/*
  * out[i,:] = self_coef * self_rows[i,:] + sum_{k in row i} w_k * msg_k
  *   msg_k = x[col[k],:]                                   (edge_emb == NULL : GINConv)
  *         = relu(x[col[k],:] + edge_emb[eid[k],:])         (edge_emb != NULL : GINEConv)
  *   w_k   = att[eid[k]]  (att == NULL -> 1)
  * replaces: GINConv.forward/message and GINEConv.forward/message up to `self.nn`
  *           (src/models/conv_layers.py:14-34, 37-66): index_select + mul + scatter_sum + add.
- * x, self_rows: [N,H]; att: [E] nullable; edge_emb: [E,H] nullable; rowptr int32[N+1];
- * col, eid: int32[E]; out: [N,H].  self_rows may be NULL (-> x).  H % 4 == 0, H <= 2048.
+ * x: [*,H]; self_rows: [N,H] (NULL -> x; not read when self_coef == 0); att: [E] nullable;
+ * edge_emb: [E,H] nullable; rowptr int32[N+1]; col, eid: int32[E]; out: [N,H].  H % 4 == 0, H <= 2048.
+ * chunk_ptr / partial: long-row support (both nullable together), see above.
  */
 int gsat_aggr_sum_fwd(const float* x, const float* self_rows, const float* att, const float* edge_emb,
                       const int32_t* rowptr, const int32_t* col, const int32_t* eid,
-                      int64_t num_rows, int64_t H, float self_coef, float* out, void* stream);
+                      int64_t num_rows, int64_t num_edges, int64_t H, float self_coef, float* out,
+                      const int32_t* chunk_ptr, float* partial, void* stream);
 
 /*
  * Backward of gsat_aggr_sum_fwd over the TRANSPOSED structure (edges grouped by source node j):
@@ -105,12 +121,13 @@ int gsat_aggr_sum_fwd(const float* x, const float* self_rows, const float* att, 
  *   datt[eid[k]]        = < msg_k , dout[dst[k],:] >
  *   dedge_emb[eid[k],:] = att_k * dout[dst[k],:] * [pre_k > 0]        (GINE only)
  * replaces: autograd backward of the above (example/trainer.py:34, src/run_gsat.py:634).
- * rowptr_src int32[N+1]; dst_sorted, eid_src int32[E]; datt nullable; dedge_emb nullable.
+ * rowptr_src int32[N+1]; dst_sorted, eid_src int32[E]; datt nullable; dedge_emb nullable;
+ * chunk_ptr / partial: long-row support for the by-source CSR.
  */
 int gsat_aggr_sum_bwd(const float* x, const float* att, const float* edge_emb, const float* dout,
                       const int32_t* rowptr_src, const int32_t* dst_sorted, const int32_t* eid_src,
-                      int64_t num_rows, int64_t H, float self_coef, float* dx, float* datt,
-                      float* dedge_emb, void* stream);
+                      int64_t num_rows, int64_t num_edges, int64_t H, float self_coef, float* dx, float* datt,
+                      float* dedge_emb, const int32_t* chunk_ptr, float* partial, void* stream);
 
 /* ============================ masked message passing: PNA multi-aggregation ================== */
 
@@ -216,6 +233,8 @@ typedef struct gsat_attn_args {
     float* stats;              /* [G*(2*C1+2*C2)] saved: mean1 | rstd1 | mean2 | rstd2 */
     float* logits;             /* [M] out */
     float* att;                /* [M] out, nullable */
+    void* fwd_workspace;       /* gsat_attn_fwd_workspace_bytes() bytes (0 for batches of small graphs) */
+    size_t fwd_workspace_bytes;
 } gsat_attn_args;
 
 typedef struct gsat_attn_grads {
@@ -225,11 +244,14 @@ typedef struct gsat_attn_grads {
     const int32_t* eid_by_src;
     const int32_t* rowptr_dst; /* edge mode: by-destination CSR + edge ids */
     const int32_t* eid_by_dst;
+    const int32_t* chunk_ptr_src; /* nullable: long-row chunks of the two CSRs (gsat_row_chunks) */
+    const int32_t* chunk_ptr_dst;
     float *demb, *dW1, *db1, *dW2, *db2, *dW3, *db3;
     void* workspace;
     size_t workspace_bytes;
 } gsat_attn_grads;
 
+size_t gsat_attn_fwd_workspace_bytes(const gsat_attn_args* args);
 size_t gsat_attn_bwd_workspace_bytes(const gsat_attn_args* args);
 int gsat_attn_fwd(const gsat_attn_args* args, void* stream);
 int gsat_attn_bwd(const gsat_attn_args* args, const gsat_attn_grads* grads, void* stream);

@@ -1,0 +1,141 @@
+"""-m gpu: power-law rows (hubs split into 256-edge chunks) and few huge graphs, vs the oracle."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import bookkeeping as obk
+from oracle import modules as om
+from oracle import ops as oops
+from tests.util import close
+
+pytestmark = pytest.mark.gpu
+
+
+def hub_graph(seed, n=2500, hubs=(0, 5), hub_deg=(1500, 300), extra=2000):
+    """Undirected multigraph-free graph where node 0 has ~1500 neighbours, node 5 ~300 (> and ~ the 256 chunk)."""
+    rng = np.random.RandomState(seed)
+    es = set()
+    for h, d in zip(hubs, hub_deg):
+        for v in rng.choice(np.arange(n), size=min(d, n - 1), replace=False):
+            if v != h:
+                es.add((min(h, int(v)), max(h, int(v))))
+    while len(es) < sum(hub_deg) // 2 + extra:
+        a, b = rng.randint(0, n, size=2)
+        if a != b:
+            es.add((int(min(a, b)), int(max(a, b))))
+    und = np.array(sorted(es), dtype=np.int64).T
+    ei = np.concatenate([und, und[::-1]], axis=1)
+    perm = rng.permutation(ei.shape[1])
+    return torch.from_numpy(ei[:, perm]).contiguous(), n
+
+
+@pytest.mark.parametrize("H", [16, 64, 256, 512])
+@pytest.mark.parametrize("gine", [False, True])
+def test_sum_aggregate_with_hubs(dev, H, gine):
+    from dp_gsat_amd.graph_index import BatchIndex
+    from dp_gsat_amd.ops import masked_sum_aggregate
+    ei, N = hub_graph(1)
+    E = ei.shape[1]
+    assert torch.bincount(ei[1]).max() > 3 * 256
+    g = torch.Generator().manual_seed(H)
+    x, att, go = torch.randn(N, H, generator=g), torch.rand(E, 1, generator=g), torch.randn(N, H, generator=g)
+    ee = torch.randn(E, H, generator=g) if gine else None
+    ref = {}
+    for dt in (torch.float32, torch.float64):
+        xo, ao = x.to(dt).clone().requires_grad_(True), att.to(dt).clone().requires_grad_(True)
+        eo = ee.to(dt).clone().requires_grad_(True) if gine else None
+        oo = oops.gine_aggregate(xo, ei, eo, ao) if gine else oops.gin_aggregate(xo, ei, ao)
+        oo.backward(go.to(dt))
+        ref[dt] = (oo, xo.grad, ao.grad, eo.grad if gine else None)
+    ix = BatchIndex(ei.to(dev), N)
+    assert int(ix.chunk_ptr_dst[-1]) >= 6 + 2        # node 0: >= 6 chunks, node 5: 2 chunks
+    xd, ad = x.to(dev).requires_grad_(True), att.to(dev).requires_grad_(True)
+    ed = ee.to(dev).requires_grad_(True) if gine else None
+    od = masked_sum_aggregate(xd, ix, ad, ed)
+    od.backward(go.to(dev))
+    r32, r64 = ref[torch.float32], ref[torch.float64]
+    close(od, r32[0], ref64=r64[0], what="out")
+    close(xd.grad, r32[1], ref64=r64[1], what="dx")
+    close(ad.grad, r32[2], ref64=r64[2], what="datt")
+    if gine:
+        close(ed.grad, r32[3], ref64=r64[3], what="dedge")
+    # bitwise reproducible with chunked rows too
+    od2 = masked_sum_aggregate(x.to(dev), ix, att.to(dev), ee.to(dev) if gine else None)
+    assert torch.equal(od2, od.detach())
+
+
+def test_gsat_step_on_powerlaw_two_graphs(dev):
+    """C5-shaped: few large power-law graphs, GIN + edge attention (symmetrised), H=32."""
+    import dp_gsat_amd as G
+    from dp_gsat_amd import synth
+    from tests.test_gpu_models import _mk_pair, _step
+    data = synth.powerlaw_batch(num_nodes=3000, num_edges=30000, num_graphs=2, seed=3, x_dim=8)
+    assert torch.bincount(data.edge_index[1]).max() > 256
+    H = 32
+    cfg = dict(model_name="GIN", n_layers=2, hidden_size=H, dropout_p=0.0)
+    # duplicate edges exist in Chung-Lu sampling: symmetrisation pairs them in stable order on both sides
+    pair = _mk_pair(G, "GIN", cfg, 8, 0, H, True, dev)
+    _step(G, data, *pair, True, H, dev, True)
+
+
+def test_pna_and_lift_with_hubs(dev):
+    from dp_gsat_amd.graph_index import BatchIndex
+    from dp_gsat_amd.ops import pna_aggregate
+    import dp_gsat_amd as G
+    ei, N = hub_graph(2, n=1200, hub_deg=(900, 280), extra=800)
+    E = ei.shape[1]
+    H = 16
+    g = torch.Generator().manual_seed(0)
+    x, na, go = torch.randn(N, H, generator=g), torch.rand(N, 1, generator=g), torch.randn(N, 8 * H, generator=g)
+    ref = {}
+    for dt in (torch.float32, torch.float64):
+        xo, no = x.to(dt).clone().requires_grad_(True), na.to(dt).clone().requires_grad_(True)
+        ea = oops.lift_node_att_to_edge_att(no, ei)
+        oo = oops.pna_aggregate(xo, ei, ea, ["mean", "min", "max", "std"], ["identity"], {"lin": 1.0, "log": 1.0})
+        oo.backward(go.to(dt))
+        ref[dt] = (oo, xo.grad, no.grad)
+    ix = BatchIndex(ei.to(dev), N)
+    xd, nd = x.to(dev).requires_grad_(True), na.to(dev).requires_grad_(True)
+    ead = G.lift_node_att_to_edge_att(nd, ei.to(dev))
+    od = pna_aggregate(xd, ix, ead, None, ["mean", "min", "max", "std"], ["identity"], {"lin": 1.0, "log": 1.0})
+    od.backward(go.to(dev))
+    r32, r64 = ref[torch.float32], ref[torch.float64]
+    close(od, r32[0], ref64=r64[0], what="out")
+    close(xd.grad, r32[1], ref64=r64[1], what="dx")
+    close(nd.grad, r32[2], ref64=r64[2], what="dnode_att")
+
+
+def test_extractor_with_sliced_segments(dev):
+    """Two graphs with > 4096 rows each: the segmented statistics run in row slices + ordered combine (Z > 1)."""
+    import dp_gsat_amd as G
+    from dp_gsat_amd import synth
+    data = synth.powerlaw_batch(num_nodes=12000, num_edges=40000, num_graphs=2, seed=5, x_dim=8)
+    H = 16
+    for edge_mode in (True, False):
+        M = data.num_edges if edge_mode else data.num_nodes
+        assert M // 2 > 4096
+        g = torch.Generator().manual_seed(1)
+        emb = torch.randn(data.num_nodes, H, generator=g)
+        C1 = 4 * H if edge_mode else 2 * H
+        masks = [(torch.rand(M, C1, generator=g) > 0.5).float(), (torch.rand(M, H, generator=g) > 0.5).float()]
+        u = torch.rand(M, 1, generator=g).clamp_(1e-10, 1 - 1e-10)
+        ga = torch.randn(M, 1, generator=g)
+        oext = om.ExtractorMLP(H, edge_mode).train()
+        ref = {}
+        for dt in (torch.float32, torch.float64):
+            ext = om.ExtractorMLP(H, edge_mode).to(dt).train()
+            ext.load_state_dict({k: v.to(dt) for k, v in oext.state_dict().items()})
+            e = emb.to(dt).clone().requires_grad_(True)
+            a = oops.concrete_sample(ext(e, data.edge_index, data.batch, masks=[m.to(dt) for m in masks]), u.to(dt), True)
+            a.backward(ga.to(dt))
+            ref[dt] = dict(a=a, demb=e.grad, **{k: p.grad for k, p in ext.named_parameters()})
+        ext = G.ExtractorMLP(H, edge_mode).to(dev).train()
+        ext.load_state_dict(oext.state_dict())
+        ed = emb.to(dev).requires_grad_(True)
+        _, a = ext.attend(ed, data.edge_index.to(dev), data.batch.to(dev), noise=u.to(dev), dropout_masks=[m.to(dev) for m in masks])
+        a.backward(ga.to(dev))
+        r32, r64 = ref[torch.float32], ref[torch.float64]
+        close(a, r32["a"], ref64=r64["a"], what="att")
+        close(ed.grad, r32["demb"], ref64=r64["demb"], what="demb")
+        for k, p in ext.named_parameters():
+            close(p.grad, r32[k], ref64=r64[k], what=k)
