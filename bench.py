@@ -223,8 +223,15 @@ def aggregation_roofline(wl, data, dev, reps=30, rounds=5):
         best.append(start.elapsed_time(end) * 1e-3 / reps)
     t = float(np.median(best))
     achieved = alg_bytes / t / 1e9
+    traffic = None          # HBM bytes per launch from rocprofv3 PMC passes (offline, profiles/pmc_traffic.json), same shape only
+    try:
+        rec = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json"))).get(wl.get("key", ""))
+        if rec and rec["algorithmic_bytes_per_launch"] == int(alg_bytes):
+            traffic = rec["traffic_bytes_per_launch"]
+    except (OSError, ValueError, KeyError):
+        pass
     return dict(bound="hbm", kernel=kname, achieved=round(achieved, 1), peak=HBM_PEAK_GBS, unit="GB/s",
-                frac=round(achieved / HBM_PEAK_GBS, 4), traffic=None, alg_bytes_per_launch=int(alg_bytes),
+                frac=round(achieved / HBM_PEAK_GBS, 4), traffic=traffic, alg_bytes_per_launch=int(alg_bytes),
                 us_per_launch=round(t * 1e6, 2), nodes=N, edges=E)
 
 
@@ -298,6 +305,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-full-step", action="store_true")
     ap.add_argument("--cpu-sample-graphs", type=int, default=0)
+    ap.add_argument("--roofline-only", action="store_true", help="only run the aggregation-kernel roofline leg (for rocprofv3 --pmc passes)")
+    ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only to rehearse N>1 on one GPU)")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -306,11 +315,14 @@ def main():
     distributed = world > 1
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the HIP path has no CPU fallback")
-    dev = torch.device("cuda", local_rank)
+    dev = torch.device("cuda", local_rank % max(torch.cuda.device_count(), 1))
     torch.cuda.set_device(dev)
     if distributed:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        else:
+            dist.init_process_group(args.backend, rank=rank, world_size=world)
     if args.gpus != world and rank == 0:
         print(f"[bench] note: --gpus {args.gpus} but WORLD_SIZE={world}; using WORLD_SIZE", file=sys.stderr)
 
@@ -322,11 +334,14 @@ def main():
         dist.barrier()
     _lib.load()
 
-    wl = WORKLOADS[args.workload]
+    wl = dict(WORKLOADS[args.workload], key=args.workload)
     host_batch, x_dim, e_dim = local_shard(args.workload, wl["graphs"], rank, world, args.seed)
     data = host_batch.to(dev)
     torch.manual_seed(args.seed + rank)
 
+    if args.roofline_only:
+        print(json.dumps({"roofline": aggregation_roofline(wl, data, dev, reps=10, rounds=2)}))
+        return
     hot = HotPath(wl, data, dev, seed=args.seed + rank)
     hot.reuse_index = args.reuse_index
     if distributed:
