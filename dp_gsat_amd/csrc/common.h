@@ -74,6 +74,12 @@ template <int WIDTH> __device__ __forceinline__ float group_sum(float v) {
 
 __device__ __forceinline__ float4 ld4(const float* p) { return *reinterpret_cast<const float4*>(p); }
 __device__ __forceinline__ void st4(float* p, float4 v) { *reinterpret_cast<float4*>(p) = v; }
+// streaming (non-temporal) 16-byte store for outputs that are written once and not re-read by this kernel
+__device__ __forceinline__ void st4_nt(float* p, float4 v) {
+    typedef float v4f __attribute__((ext_vector_type(4)));
+    v4f t = {v.x, v.y, v.z, v.w};
+    __builtin_nontemporal_store(t, reinterpret_cast<v4f*>(p));
+}
 __device__ __forceinline__ float4 f4zero() { return make_float4(0.f, 0.f, 0.f, 0.f); }
 __device__ __forceinline__ float4 f4fma(float a, float4 x, float4 acc) {
     acc.x = fmaf(a, x.x, acc.x); acc.y = fmaf(a, x.y, acc.y);

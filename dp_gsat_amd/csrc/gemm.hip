@@ -19,25 +19,27 @@ namespace gsat {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
-constexpr int GM = 128, GN = 128, GK = 32, GT = 256;
+constexpr int GM = 128, GK = 32, GT = 256;      // block tile GM x (64*TN) x GK, TN = 1 | 2
 constexpr int LD_KC = 129;   // k-contiguous source: transposing scalar stores, odd stride -> conflict-free
 constexpr int LD_KM = 132;   // k-major source: 16-byte vector stores need a multiple of 4
 
 // stage one 128(rows) x 32(k) slab of a k-contiguous operand:  4 float4 per thread
-struct StageKC { float4 v[4]; };
+struct StageKC { float4 v[4]; };   // 128 (or 64: two entries unused) rows/columns x 32 k
 // X[r][k], r in [r0, r0+128), k in [k0, k0+32): thread t -> row (t>>3) + 32p, k-quad t&7
+template <int ROWS>
 __device__ __forceinline__ void load_kcontig(StageKC& s, const float* __restrict__ X, int64_t ld, int r0, int R, int k0, int K, int t) {
     const int kq = (t & 7) * 4;
 #pragma unroll
-    for (int p = 0; p < 4; ++p) {
+    for (int p = 0; p < ROWS / 32; ++p) {
         const int r = r0 + (t >> 3) + 32 * p;
         s.v[p] = (r < R && k0 + kq < K) ? ld4(X + (size_t)r * ld + k0 + kq) : f4zero();
     }
 }
+template <int ROWS>
 __device__ __forceinline__ void store_kcontig(const StageKC& s, float* __restrict__ L, int t) {   // L[k][LD_KC]
     const int kq = (t & 7) * 4;
 #pragma unroll
-    for (int p = 0; p < 4; ++p) {
+    for (int p = 0; p < ROWS / 32; ++p) {
         const int r = (t >> 3) + 32 * p;
         L[(kq + 0) * LD_KC + r] = s.v[p].x;
         L[(kq + 1) * LD_KC + r] = s.v[p].y;
@@ -45,25 +47,30 @@ __device__ __forceinline__ void store_kcontig(const StageKC& s, float* __restric
         L[(kq + 3) * LD_KC + r] = s.v[p].w;
     }
 }
-// X[k][c], k in [k0,k0+32), c in [c0,c0+128): thread t -> k (t>>5) + 8p, column quad t&31
+// X[k][c], k in [k0,k0+32), c in [c0,c0+COLS): thread t -> k (t / (COLS/4)) + (1024/COLS) p, column quad t % (COLS/4)
+template <int COLS>
 __device__ __forceinline__ void load_kmajor(StageKC& s, const float* __restrict__ X, int64_t ld, int c0, int Ccols, int k0, int K, int t) {
-    const int cq = (t & 31) * 4;
+    constexpr int QPR = COLS / 4, KPP = GT / QPR;          // quads per k-row, k-rows per pass
+    const int cq = (t % QPR) * 4;
 #pragma unroll
-    for (int p = 0; p < 4; ++p) {
-        const int k = k0 + (t >> 5) + 8 * p;
+    for (int p = 0; p < GK / KPP; ++p) {
+        const int k = k0 + t / QPR + KPP * p;
         s.v[p] = (k < K && c0 + cq < Ccols) ? ld4(X + (size_t)k * ld + c0 + cq) : f4zero();
     }
 }
+template <int COLS>
 __device__ __forceinline__ void store_kmajor(const StageKC& s, float* __restrict__ L, int t) {
-    const int cq = (t & 31) * 4;
+    constexpr int QPR = COLS / 4, KPP = GT / QPR;
+    const int cq = (t % QPR) * 4;
 #pragma unroll
-    for (int p = 0; p < 4; ++p) st4(L + ((t >> 5) + 8 * p) * LD_KM + cq, s.v[p]);
+    for (int p = 0; p < GK / KPP; ++p) st4(L + (t / QPR + KPP * p) * LD_KM + cq, s.v[p]);
 }
 
-template <bool A_T, bool B_T>
+template <bool A_T, bool B_T, int TN>
 __global__ __launch_bounds__(GT) void k_gemm_f32(const float* __restrict__ A, int64_t lda, const float* __restrict__ B, int64_t ldb,
                                                  float* __restrict__ C, int64_t ldc, int M, int N, int K, int k_per_split,
                                                  const float* __restrict__ bias, int accumulate, size_t slab_stride) {
+    constexpr int GN = 64 * TN;
     constexpr int LDA = A_T ? LD_KM : LD_KC, LDB = B_T ? LD_KC : LD_KM;
     __shared__ __attribute__((aligned(16))) float As[GK * LDA];
     __shared__ __attribute__((aligned(16))) float Bs[GK * LDB];
@@ -71,29 +78,29 @@ __global__ __launch_bounds__(GT) void k_gemm_f32(const float* __restrict__ A, in
     const int wm = wave >> 1, wn = wave & 1;
     const int m0 = blockIdx.y * GM, n0 = blockIdx.x * GN;
     const int kbeg = blockIdx.z * k_per_split, kend = min(K, kbeg + k_per_split);
-    f32x16 acc[2][2];
+    f32x16 acc[2][TN];
 #pragma unroll
     for (int i = 0; i < 2; ++i)
 #pragma unroll
-        for (int j = 0; j < 2; ++j)
+        for (int j = 0; j < TN; ++j)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
     StageKC sa, sb;
     auto gload = [&](int k0) {
-        if (A_T) load_kmajor(sa, A, lda, m0, M, k0, kend, t); else load_kcontig(sa, A, lda, m0, M, k0, kend, t);
-        if (B_T) load_kcontig(sb, B, ldb, n0, N, k0, kend, t); else load_kmajor(sb, B, ldb, n0, N, k0, kend, t);
+        if (A_T) load_kmajor<GM>(sa, A, lda, m0, M, k0, kend, t); else load_kcontig<GM>(sa, A, lda, m0, M, k0, kend, t);
+        if (B_T) load_kcontig<GN>(sb, B, ldb, n0, N, k0, kend, t); else load_kmajor<GN>(sb, B, ldb, n0, N, k0, kend, t);
     };
     auto lstore = [&]() {
-        if (A_T) store_kmajor(sa, As, t); else store_kcontig(sa, As, t);
-        if (B_T) store_kcontig(sb, Bs, t); else store_kmajor(sb, Bs, t);
+        if (A_T) store_kmajor<GM>(sa, As, t); else store_kcontig<GM>(sa, As, t);
+        if (B_T) store_kcontig<GN>(sb, Bs, t); else store_kmajor<GN>(sb, Bs, t);
     };
     if (kbeg < kend) {
         gload(kbeg);
         lstore();
     }
     __syncthreads();
-    const int arow = wm * 64 + (lane & 31), bcol = wn * 64 + (lane & 31), kh = lane >> 5;
+    const int arow = wm * 64 + (lane & 31), bcol = wn * 32 * TN + (lane & 31), kh = lane >> 5;
     for (int k0 = kbeg; k0 < kend; k0 += GK) {
         const bool more = k0 + GK < kend;
         if (more) gload(k0 + GK);                       // next slab's global loads fly under this slab's MFMAs
@@ -101,11 +108,14 @@ __global__ __launch_bounds__(GT) void k_gemm_f32(const float* __restrict__ A, in
         for (int kk = 0; kk < GK / 2; ++kk) {
             const int ka = (2 * kk + kh) * LDA, kb = (2 * kk + kh) * LDB;
             const float a0 = As[ka + arow], a1 = As[ka + arow + 32];
-            const float b0 = Bs[kb + bcol], b1 = Bs[kb + bcol + 32];
-            acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc[0][0], 0, 0, 0);
-            acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, acc[0][1], 0, 0, 0);
-            acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc[1][0], 0, 0, 0);
-            acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc[1][1], 0, 0, 0);
+            float b[TN];
+#pragma unroll
+            for (int j = 0; j < TN; ++j) b[j] = Bs[kb + bcol + 32 * j];
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+                acc[0][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b[j], acc[0][j], 0, 0, 0);
+                acc[1][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b[j], acc[1][j], 0, 0, 0);
+            }
         }
         __syncthreads();                                // every wave is done reading this slab
         if (more) lstore();
@@ -116,8 +126,8 @@ __global__ __launch_bounds__(GT) void k_gemm_f32(const float* __restrict__ A, in
 #pragma unroll
     for (int i = 0; i < 2; ++i)
 #pragma unroll
-        for (int j = 0; j < 2; ++j) {
-            const int col = n0 + wn * 64 + j * 32 + (lane & 31);
+        for (int j = 0; j < TN; ++j) {
+            const int col = n0 + wn * 32 * TN + j * 32 + (lane & 31);
             if (col >= N) continue;
             const float bv = bias ? bias[col] : 0.f;
 #pragma unroll
@@ -152,12 +162,21 @@ __global__ void k_slab_reduce(const float* __restrict__ slabs, int nslab, size_t
     *p = accumulate ? *p + acc : acc;
 }
 
+// Tile choice: 128x128 blocks (3 resident per CU) unless the grid quantises badly on 256 CUs, then 128x64 blocks
+// (half the work each, 4 resident per CU).  cost ~ rounds x work per block.
+static int gemm_tn(int64_t M, int64_t N) {
+    if (N <= 64) return 1;
+    const int64_t b2 = ceil_div(M, GM) * ceil_div(N, 128), b1 = ceil_div(M, GM) * ceil_div(N, 64);
+    const int64_t cost2 = ceil_div(b2, 256 * 3) * 2, cost1 = ceil_div(b1, 256 * 4) * 1;
+    return cost1 < cost2 ? 1 : 2;
+}
+
 // number of K splits used for an M x N output reduced over K rows (shared by the workspace query)
 int gemm_splits(int64_t M, int64_t N, int64_t K, bool reduce_rows) {
     if (!reduce_rows) return 1;                       // only weight gradients (K = #rows) are split
-    const int64_t tiles = ceil_div(M, GM) * ceil_div(N, GN);
+    const int64_t tiles = ceil_div(M, GM) * ceil_div(N, 128);
     if (tiles >= 256 || K <= 4 * GK) return 1;
-    int64_t s = std::min<int64_t>(ceil_div(1024, tiles), ceil_div(K, 8 * GK));
+    int64_t s = std::min<int64_t>(ceil_div(768, tiles), ceil_div(K, 8 * GK));
     return (int)std::max<int64_t>(1, std::min<int64_t>(s, 512));
 }
 
@@ -176,7 +195,8 @@ int gemm_f32(hipStream_t stream, bool a_t, bool b_t, int64_t M, int64_t N, int64
                  "gemm_f32: contiguous extents and leading dimensions must be multiples of 4 (M=%lld N=%lld K=%lld)", (long long)M, (long long)N, (long long)K);
     GSAT_REQUIRE(((uintptr_t)A % 16 == 0) && ((uintptr_t)B % 16 == 0), GSAT_ERR_ARG, "gemm_f32: operands must be 16-byte aligned");
     const int splits = gemm_splits(M, N, K, a_t);
-    dim3 grid((unsigned)ceil_div(N, GN), (unsigned)ceil_div(M, GM), (unsigned)splits);
+    const int tn = splits > 1 ? 2 : gemm_tn(M, N);
+    dim3 grid((unsigned)ceil_div(N, 64 * tn), (unsigned)ceil_div(M, GM), (unsigned)splits);
     int kps = (int)(ceil_div(ceil_div(K, splits), GK) * GK);
     float* out = C;
     int64_t ldo = ldc;
@@ -188,7 +208,11 @@ int gemm_f32(hipStream_t stream, bool a_t, bool b_t, int64_t M, int64_t N, int64
         GSAT_REQUIRE(!bias, GSAT_ERR_UNSUPPORTED, "gemm_f32: bias with split-K");
         out = ws; ldo = N; slab = (size_t)M * N; acc_flag = 0;
     }
-#define LAUNCH(AT, BT) k_gemm_f32<AT, BT><<<grid, GT, 0, stream>>>(A, lda, B, ldb, out, ldo, (int)M, (int)N, (int)K, kps, bptr, acc_flag, slab)
+#define LAUNCH(AT, BT)                                                                                                              \
+    do {                                                                                                                            \
+        if (tn == 2) k_gemm_f32<AT, BT, 2><<<grid, GT, 0, stream>>>(A, lda, B, ldb, out, ldo, (int)M, (int)N, (int)K, kps, bptr, acc_flag, slab); \
+        else k_gemm_f32<AT, BT, 1><<<grid, GT, 0, stream>>>(A, lda, B, ldb, out, ldo, (int)M, (int)N, (int)K, kps, bptr, acc_flag, slab);         \
+    } while (0)
     if (a_t) { if (b_t) LAUNCH(true, true); else LAUNCH(true, false); }
     else { if (b_t) LAUNCH(false, true); else LAUNCH(false, false); }
 #undef LAUNCH

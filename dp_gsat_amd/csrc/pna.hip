@@ -110,14 +110,31 @@ __global__ __launch_bounds__(PNA_BLOCK) void k_pna_fwd(
         Acc4 aj, ae;
         aj.init(); ae.init();
         const float4 xi = on ? ld4(x + (size_t)row * H + c) : f4zero();
-        for (int k = beg; k < end; ++k) {
-            const int j = col[k];
-            const int e = (att != nullptr || HAS_EE) ? eid[k] : 0;
-            const float w = att ? att[e] : 1.f;
-            sa += w; sa2 = fmaf(w, w, sa2); amin = fminf(amin, w); amax = fmaxf(amax, w);
-            if (on) {
-                aj.add(f4scale(w, ld4(x + (size_t)j * H + c)));
-                if (HAS_EE) ae.add(f4scale(w, ld4(edge_emb + (size_t)e * H + c)));
+        for (int k = beg; k < end; k += 4) {       // batches of 4 in-edges: all index / att / row loads issued together
+            const int nb = min(4, end - k);
+            int j[4], e[4];
+            float w[4];
+            float4 xv[4], ev[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                j[u] = u < nb ? col[k + u] : 0;
+                e[u] = (u < nb && (att != nullptr || HAS_EE)) ? eid[k + u] : 0;
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                w[u] = (u < nb && att) ? att[e[u]] : 1.f;
+                xv[u] = (u < nb && on) ? ld4(x + (size_t)j[u] * H + c) : f4zero();
+                if (HAS_EE) ev[u] = (u < nb && on) ? ld4(edge_emb + (size_t)e[u] * H + c) : f4zero();
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                if (u < nb) {
+                    sa += w[u]; sa2 = fmaf(w[u], w[u], sa2); amin = fminf(amin, w[u]); amax = fmaxf(amax, w[u]);
+                    if (on) {
+                        aj.add(f4scale(w[u], xv[u]));
+                        if (HAS_EE) ae.add(f4scale(w[u], ev[u]));
+                    }
+                }
             }
         }
         if (!on) continue;
@@ -127,27 +144,12 @@ __global__ __launch_bounds__(PNA_BLOCK) void k_pna_fwd(
             const float f = scaler_factor(cfg.scal[s], cnt, cfg.avg_lin, cfg.avg_log);
             for (int a = 0; a < cfg.A; ++a) {
                 float* o = orow + (size_t)(s * cfg.A + a) * F + c;
-                st4(o, f4scale(f, agg_value4(cfg.aggr[a], ai, cnt)));
-                st4(o + H, f4scale(f, agg_value4(cfg.aggr[a], aj, cnt)));
-                if (HAS_EE) st4(o + 2 * H, f4scale(f, agg_value4(cfg.aggr[a], ae, cnt)));
+                st4_nt(o, f4scale(f, agg_value4(cfg.aggr[a], ai, cnt)));
+                st4_nt(o + H, f4scale(f, agg_value4(cfg.aggr[a], aj, cnt)));
+                if (HAS_EE) st4_nt(o + 2 * H, f4scale(f, agg_value4(cfg.aggr[a], ae, cnt)));
             }
         }
     }
-}
-
-// per-channel gradient routing coefficients:  d m_k = P + Q*m_k + gmin*[k==argmin] + gmax*[k==argmax]
-struct Coef4 { float4 P, Q, gmin, gmax; };
-
-__device__ __forceinline__ void coef_scalar(float gs, float gm, float gmn, float gmx, float gv, float gsd, float s, float q,
-                                            float cnt, float* P, float* Q) {
-    const float n = fmaxf(cnt, 1.f);
-    const float mean = s / n, msq = q / n;
-    const float var = msq - mean * mean;
-    const float sd = sqrtf(fmaxf(var, 0.f) + 1e-5f);
-    const float gvt = gv + (var > 0.f ? gsd / (2.f * sd) : 0.f);
-    *P = gs + gm / n - 2.f * mean * gvt / n;
-    *Q = 2.f * gvt / n;
-    (void)gmn; (void)gmx;
 }
 
 template <int LPR, bool HAS_EE>
@@ -173,33 +175,6 @@ __global__ __launch_bounds__(PNA_BLOCK) void k_pna_bwd_dst(
             if (on) st4(dx_self + (size_t)row * H + c, f4zero());
             continue;
         }
-        // ---- fold the scalers: per aggregator KIND, per message part, the upstream gradient ----
-        float4 g[6][HAS_EE ? 3 : 2];
-#pragma unroll
-        for (int kd = 0; kd < 6; ++kd)
-#pragma unroll
-            for (int p = 0; p < parts; ++p) g[kd][p] = f4zero();
-        if (on) {
-            const float* drow = dout + (size_t)row * out_stride;
-            for (int s = 0; s < cfg.S; ++s) {
-                const float f = scaler_factor(cfg.scal[s], cnt, cfg.avg_lin, cfg.avg_log);
-                for (int a = 0; a < cfg.A; ++a) {
-                    const float* d = drow + (size_t)(s * cfg.A + a) * F + c;
-                    const int kd = cfg.aggr[a];
-#pragma unroll
-                    for (int kk = 0; kk < 6; ++kk) {
-                        if (kk == kd) {
-#pragma unroll
-                            for (int p = 0; p < parts; ++p) {
-                                float4 v = ld4(d + p * H);
-                                g[kk][p].x = fmaf(f, v.x, g[kk][p].x); g[kk][p].y = fmaf(f, v.y, g[kk][p].y);
-                                g[kk][p].z = fmaf(f, v.z, g[kk][p].z); g[kk][p].w = fmaf(f, v.w, g[kk][p].w);
-                            }
-                        }
-                    }
-                }
-            }
-        }
         // ---- pass 1: row statistics and first-occurrence args ---------------------------------
         float sa = 0.f, sa2 = 0.f, amin = INFINITY, amax = -INFINITY;
         int kmin_a = beg, kmax_a = beg;
@@ -207,23 +182,45 @@ __global__ __launch_bounds__(PNA_BLOCK) void k_pna_bwd_dst(
         aj.init(); ae.init();
         int4 jmin = make_int4(beg, beg, beg, beg), jmax = jmin, emin = jmin, emax = jmin;
         const float4 xi = on ? ld4(x + (size_t)row * H + c) : f4zero();
-        for (int k = beg; k < end; ++k) {
-            const int j = col[k];
-            const int e = (att != nullptr || HAS_EE) ? eid[k] : 0;
-            const float w = att ? att[e] : 1.f;
-            sa += w; sa2 = fmaf(w, w, sa2);
-            if (w < amin) { amin = w; kmin_a = k; }
-            if (w > amax) { amax = w; kmax_a = k; }
-            if (on) {
-                float4 m = f4scale(w, ld4(x + (size_t)j * H + c));
-                if (m.x < aj.mn.x) jmin.x = k; if (m.y < aj.mn.y) jmin.y = k; if (m.z < aj.mn.z) jmin.z = k; if (m.w < aj.mn.w) jmin.w = k;
-                if (m.x > aj.mx.x) jmax.x = k; if (m.y > aj.mx.y) jmax.y = k; if (m.z > aj.mx.z) jmax.z = k; if (m.w > aj.mx.w) jmax.w = k;
-                aj.add(m);
-                if (HAS_EE) {
-                    float4 me = f4scale(w, ld4(edge_emb + (size_t)e * H + c));
-                    if (me.x < ae.mn.x) emin.x = k; if (me.y < ae.mn.y) emin.y = k; if (me.z < ae.mn.z) emin.z = k; if (me.w < ae.mn.w) emin.w = k;
-                    if (me.x > ae.mx.x) emax.x = k; if (me.y > ae.mx.y) emax.y = k; if (me.z > ae.mx.z) emax.z = k; if (me.w > ae.mx.w) emax.w = k;
-                    ae.add(me);
+        int lj[4] = {0, 0, 0, 0}, le[4] = {0, 0, 0, 0};      // indices / weights of the last batch: rows with <= 4 in-edges
+        float lw[4] = {1.f, 1.f, 1.f, 1.f};                   // (all of a molecule graph) skip the second index + att round trip
+        for (int k = beg; k < end; k += 4) {
+            const int nb = min(4, end - k);
+            int j[4], e[4];
+            float w[4];
+            float4 xv[4], ev[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                j[u] = u < nb ? col[k + u] : 0;
+                e[u] = u < nb ? eid[k + u] : 0;
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                w[u] = (u < nb && att) ? att[e[u]] : 1.f;
+                xv[u] = (u < nb && on) ? ld4(x + (size_t)j[u] * H + c) : f4zero();
+                if (HAS_EE) ev[u] = (u < nb && on) ? ld4(edge_emb + (size_t)e[u] * H + c) : f4zero();
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) { lj[u] = j[u]; le[u] = e[u]; lw[u] = w[u]; }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                if (u < nb) {
+                    const int kk = k + u;
+                    sa += w[u]; sa2 = fmaf(w[u], w[u], sa2);
+                    if (w[u] < amin) { amin = w[u]; kmin_a = kk; }
+                    if (w[u] > amax) { amax = w[u]; kmax_a = kk; }
+                    if (on) {
+                        float4 m = f4scale(w[u], xv[u]);
+                        if (m.x < aj.mn.x) jmin.x = kk; if (m.y < aj.mn.y) jmin.y = kk; if (m.z < aj.mn.z) jmin.z = kk; if (m.w < aj.mn.w) jmin.w = kk;
+                        if (m.x > aj.mx.x) jmax.x = kk; if (m.y > aj.mx.y) jmax.y = kk; if (m.z > aj.mx.z) jmax.z = kk; if (m.w > aj.mx.w) jmax.w = kk;
+                        aj.add(m);
+                        if (HAS_EE) {
+                            float4 me = f4scale(w[u], ev[u]);
+                            if (me.x < ae.mn.x) emin.x = kk; if (me.y < ae.mn.y) emin.y = kk; if (me.z < ae.mn.z) emin.z = kk; if (me.w < ae.mn.w) emin.w = kk;
+                            if (me.x > ae.mx.x) emax.x = kk; if (me.y > ae.mx.y) emax.y = kk; if (me.z > ae.mx.z) emax.z = kk; if (me.w > ae.mx.w) emax.w = kk;
+                            ae.add(me);
+                        }
+                    }
                 }
             }
         }
@@ -234,56 +231,105 @@ __global__ __launch_bounds__(PNA_BLOCK) void k_pna_bwd_dst(
         imin.y = xi.y > 0.f ? kmin_a : (xi.y < 0.f ? kmax_a : beg); imax.y = xi.y > 0.f ? kmax_a : (xi.y < 0.f ? kmin_a : beg);
         imin.z = xi.z > 0.f ? kmin_a : (xi.z < 0.f ? kmax_a : beg); imax.z = xi.z > 0.f ? kmax_a : (xi.z < 0.f ? kmin_a : beg);
         imin.w = xi.w > 0.f ? kmin_a : (xi.w < 0.f ? kmax_a : beg); imax.w = xi.w > 0.f ? kmax_a : (xi.w < 0.f ? kmin_a : beg);
-        // ---- coefficients ---------------------------------------------------------------------
-        float4 Pi, Qi, Pj, Qj, Pe = f4zero(), Qe = f4zero();
-#define GSAT_COEF(P, Q, ACC, PART)                                                                                   \
-        coef_scalar(g[0][PART].x, g[1][PART].x, 0, 0, g[4][PART].x, g[5][PART].x, ACC.s.x, ACC.q.x, cnt, &P.x, &Q.x); \
-        coef_scalar(g[0][PART].y, g[1][PART].y, 0, 0, g[4][PART].y, g[5][PART].y, ACC.s.y, ACC.q.y, cnt, &P.y, &Q.y); \
-        coef_scalar(g[0][PART].z, g[1][PART].z, 0, 0, g[4][PART].z, g[5][PART].z, ACC.s.z, ACC.q.z, cnt, &P.z, &Q.z); \
-        coef_scalar(g[0][PART].w, g[1][PART].w, 0, 0, g[4][PART].w, g[5][PART].w, ACC.s.w, ACC.q.w, cnt, &P.w, &Q.w);
-        GSAT_COEF(Pi, Qi, ai, 0)
-        GSAT_COEF(Pj, Qj, aj, 1)
-        if (HAS_EE) { GSAT_COEF(Pe, Qe, ae, 2) }
-#undef GSAT_COEF
+        // ---- fold scalers + aggregators straight into the routing coefficients of each message part ----
+        //   d m_k = P + Q*m_k + gmin*[k==argmin] + gmax*[k==argmax]
+        float4 Pi = f4zero(), Qi = f4zero(), Pj = f4zero(), Qj = f4zero(), Pe = f4zero(), Qe = f4zero();
+        float4 gmn_i = f4zero(), gmx_i = f4zero(), gmn_j = f4zero(), gmx_j = f4zero(), gmn_e = f4zero(), gmx_e = f4zero();
+        if (on) {
+            const float n = fmaxf(cnt, 1.f), inv_n = 1.f / n;
+            const float* drow = dout + (size_t)row * out_stride + c;
+#define GSAT_FOLD(ACC, PART, P, Q, GMN, GMX)                                                                           \
+            {                                                                                                          \
+                const float4 mean = f4scale(inv_n, ACC.s);                                                             \
+                float4 var = make_float4(ACC.q.x * inv_n - mean.x * mean.x, ACC.q.y * inv_n - mean.y * mean.y,         \
+                                         ACC.q.z * inv_n - mean.z * mean.z, ACC.q.w * inv_n - mean.w * mean.w);        \
+                const float4 hs = make_float4(var.x > 0.f ? 0.5f / sqrtf(var.x + 1e-5f) : 0.f, var.y > 0.f ? 0.5f / sqrtf(var.y + 1e-5f) : 0.f, \
+                                              var.z > 0.f ? 0.5f / sqrtf(var.z + 1e-5f) : 0.f, var.w > 0.f ? 0.5f / sqrtf(var.w + 1e-5f) : 0.f); \
+                float4 p0 = f4zero(), gv = f4zero();                                                                   \
+                for (int s = 0; s < cfg.S; ++s) {                                                                      \
+                    const float f = scaler_factor(cfg.scal[s], cnt, cfg.avg_lin, cfg.avg_log);                         \
+                    for (int a = 0; a < cfg.A; ++a) {                                                                  \
+                        const float4 v = f4scale(f, ld4(drow + (size_t)(s * cfg.A + a) * F + (PART) * H));             \
+                        switch (cfg.aggr[a]) {                                                                         \
+                            case AGG_SUM: p0.x += v.x; p0.y += v.y; p0.z += v.z; p0.w += v.w; break;                   \
+                            case AGG_MEAN: p0 = f4fma(inv_n, v, p0); break;                                            \
+                            case AGG_MIN: GMN.x += v.x; GMN.y += v.y; GMN.z += v.z; GMN.w += v.w; break;               \
+                            case AGG_MAX: GMX.x += v.x; GMX.y += v.y; GMX.z += v.z; GMX.w += v.w; break;               \
+                            case AGG_VAR: gv.x += v.x; gv.y += v.y; gv.z += v.z; gv.w += v.w; break;                   \
+                            default: gv.x = fmaf(v.x, hs.x, gv.x); gv.y = fmaf(v.y, hs.y, gv.y);                       \
+                                     gv.z = fmaf(v.z, hs.z, gv.z); gv.w = fmaf(v.w, hs.w, gv.w); break;                \
+                        }                                                                                              \
+                    }                                                                                                  \
+                }                                                                                                      \
+                Q = f4scale(2.f * inv_n, gv);                                                                          \
+                P = make_float4(p0.x - mean.x * Q.x, p0.y - mean.y * Q.y, p0.z - mean.z * Q.z, p0.w - mean.w * Q.w);   \
+            }
+            GSAT_FOLD(ai, 0, Pi, Qi, gmn_i, gmx_i)
+            GSAT_FOLD(aj, 1, Pj, Qj, gmn_j, gmx_j)
+            if (HAS_EE) { GSAT_FOLD(ae, 2, Pe, Qe, gmn_e, gmx_e) }
+#undef GSAT_FOLD
+        }
         // ---- pass 2: per-edge gradients -------------------------------------------------------
         float4 dxi = f4zero();
-        for (int k = beg; k < end; ++k) {
-            const int j = col[k];
-            const int e = eid[k];
-            const float w = att ? att[e] : 1.f;
-            float da = 0.f;
-            if (on) {
-                // x_j part
-                const float4 xj = ld4(x + (size_t)j * H + c);
-                float4 dm;
-                dm.x = fmaf(Qj.x, w * xj.x, Pj.x) + (k == jmin.x ? g[2][1].x : 0.f) + (k == jmax.x ? g[3][1].x : 0.f);
-                dm.y = fmaf(Qj.y, w * xj.y, Pj.y) + (k == jmin.y ? g[2][1].y : 0.f) + (k == jmax.y ? g[3][1].y : 0.f);
-                dm.z = fmaf(Qj.z, w * xj.z, Pj.z) + (k == jmin.z ? g[2][1].z : 0.f) + (k == jmax.z ? g[3][1].z : 0.f);
-                dm.w = fmaf(Qj.w, w * xj.w, Pj.w) + (k == jmin.w ? g[2][1].w : 0.f) + (k == jmax.w ? g[3][1].w : 0.f);
-                st4(dmsg + (size_t)k * H + c, f4scale(w, dm));
-                da += f4dot(dm, xj);
-                // x_i part
-                float4 di;
-                di.x = fmaf(Qi.x, w * xi.x, Pi.x) + (k == imin.x ? g[2][0].x : 0.f) + (k == imax.x ? g[3][0].x : 0.f);
-                di.y = fmaf(Qi.y, w * xi.y, Pi.y) + (k == imin.y ? g[2][0].y : 0.f) + (k == imax.y ? g[3][0].y : 0.f);
-                di.z = fmaf(Qi.z, w * xi.z, Pi.z) + (k == imin.z ? g[2][0].z : 0.f) + (k == imax.z ? g[3][0].z : 0.f);
-                di.w = fmaf(Qi.w, w * xi.w, Pi.w) + (k == imin.w ? g[2][0].w : 0.f) + (k == imax.w ? g[3][0].w : 0.f);
-                dxi = f4fma(w, di, dxi);
-                da += f4dot(di, xi);
-                if (HAS_EE) {
-                    const float4 ee = ld4(edge_emb + (size_t)e * H + c);
-                    float4 de;
-                    de.x = fmaf(Qe.x, w * ee.x, Pe.x) + (k == emin.x ? g[2][2].x : 0.f) + (k == emax.x ? g[3][2].x : 0.f);
-                    de.y = fmaf(Qe.y, w * ee.y, Pe.y) + (k == emin.y ? g[2][2].y : 0.f) + (k == emax.y ? g[3][2].y : 0.f);
-                    de.z = fmaf(Qe.z, w * ee.z, Pe.z) + (k == emin.z ? g[2][2].z : 0.f) + (k == emax.z ? g[3][2].z : 0.f);
-                    de.w = fmaf(Qe.w, w * ee.w, Pe.w) + (k == emin.w ? g[2][2].w : 0.f) + (k == emax.w ? g[3][2].w : 0.f);
-                    if (dedge) st4(dedge + (size_t)e * H + c, f4scale(w, de));
-                    da += f4dot(de, ee);
+        for (int kb = beg; kb < end; kb += 4) {
+            const int nb = min(4, end - kb);
+            int j4[4], e4[4];
+            float w4[4];
+            float4 x4[4], ee4[4];
+            if (end - beg <= 4) {
+#pragma unroll
+                for (int u = 0; u < 4; ++u) { j4[u] = lj[u]; e4[u] = le[u]; w4[u] = lw[u]; }
+            } else {
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    j4[u] = u < nb ? col[kb + u] : 0;
+                    e4[u] = u < nb ? eid[kb + u] : 0;
                 }
+#pragma unroll
+                for (int u = 0; u < 4; ++u) w4[u] = (u < nb && att) ? att[e4[u]] : 1.f;
             }
-            if (datt) {
-                da = group_sum<LPR>(da);
-                if (lane == 0) datt[e] = da;
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                x4[u] = (u < nb && on) ? ld4(x + (size_t)j4[u] * H + c) : f4zero();      // L1/L2-hot: pass 1 just gathered these rows
+                if (HAS_EE) ee4[u] = (u < nb && on) ? ld4(edge_emb + (size_t)e4[u] * H + c) : f4zero();
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                if (u >= nb) continue;
+                const int k = kb + u, e = e4[u];
+                const float w = w4[u];
+                const float4 xj = x4[u];
+                float da = 0.f;
+                if (on) {
+                    float4 dm;
+                    dm.x = fmaf(Qj.x, w * xj.x, Pj.x) + (k == jmin.x ? gmn_j.x : 0.f) + (k == jmax.x ? gmx_j.x : 0.f);
+                    dm.y = fmaf(Qj.y, w * xj.y, Pj.y) + (k == jmin.y ? gmn_j.y : 0.f) + (k == jmax.y ? gmx_j.y : 0.f);
+                    dm.z = fmaf(Qj.z, w * xj.z, Pj.z) + (k == jmin.z ? gmn_j.z : 0.f) + (k == jmax.z ? gmx_j.z : 0.f);
+                    dm.w = fmaf(Qj.w, w * xj.w, Pj.w) + (k == jmin.w ? gmn_j.w : 0.f) + (k == jmax.w ? gmx_j.w : 0.f);
+                    st4(dmsg + (size_t)k * H + c, f4scale(w, dm));
+                    da += f4dot(dm, xj);
+                    float4 di;
+                    di.x = fmaf(Qi.x, w * xi.x, Pi.x) + (k == imin.x ? gmn_i.x : 0.f) + (k == imax.x ? gmx_i.x : 0.f);
+                    di.y = fmaf(Qi.y, w * xi.y, Pi.y) + (k == imin.y ? gmn_i.y : 0.f) + (k == imax.y ? gmx_i.y : 0.f);
+                    di.z = fmaf(Qi.z, w * xi.z, Pi.z) + (k == imin.z ? gmn_i.z : 0.f) + (k == imax.z ? gmx_i.z : 0.f);
+                    di.w = fmaf(Qi.w, w * xi.w, Pi.w) + (k == imin.w ? gmn_i.w : 0.f) + (k == imax.w ? gmx_i.w : 0.f);
+                    dxi = f4fma(w, di, dxi);
+                    da += f4dot(di, xi);
+                    if (HAS_EE) {
+                        const float4 ee = ee4[u];
+                        float4 de;
+                        de.x = fmaf(Qe.x, w * ee.x, Pe.x) + (k == emin.x ? gmn_e.x : 0.f) + (k == emax.x ? gmx_e.x : 0.f);
+                        de.y = fmaf(Qe.y, w * ee.y, Pe.y) + (k == emin.y ? gmn_e.y : 0.f) + (k == emax.y ? gmx_e.y : 0.f);
+                        de.z = fmaf(Qe.z, w * ee.z, Pe.z) + (k == emin.z ? gmn_e.z : 0.f) + (k == emax.z ? gmx_e.z : 0.f);
+                        de.w = fmaf(Qe.w, w * ee.w, Pe.w) + (k == emin.w ? gmn_e.w : 0.f) + (k == emax.w ? gmx_e.w : 0.f);
+                        if (dedge) st4(dedge + (size_t)e * H + c, f4scale(w, de));
+                        da += f4dot(de, ee);
+                    }
+                }
+                if (datt) {
+                    da = group_sum<LPR>(da);
+                    if (lane == 0) datt[e] = da;
+                }
             }
         }
         if (on) st4(dx_self + (size_t)row * H + c, dxi);
