@@ -289,3 +289,55 @@ class GSAT(nn.Module):
         loss = pred_loss + info
         loss_dict = {"loss": loss.item(), "pred": pred_loss.item(), "info": info.item()}
         return edge_att, loss, loss_dict, clf_logits, dict(emb=emb, att_log_logits=att_log_logits, att=att)
+
+
+def f1_sparsity_loss(p_uv, y_uv, eps=1e-6):
+    """src/run_gsat.py:151-180 (asserts / input() dropped)."""
+    TP = (p_uv.view(-1) * y_uv.view(-1)).sum()
+    P, G = p_uv.sum(), y_uv.sum()
+    precision, recall = TP / (P + eps), TP / (G + eps)
+    f1 = 2 * precision * recall / (precision + recall + eps)
+    return (1 - f1) + p_uv.abs().mean()
+
+
+class DualGSAT(nn.Module):
+    """src/run_gsat.py:189-281 + 121-149 with explicit randomness; plotting / host copies / eval-mode Gumbel noise dropped
+    (SURVEY App. C, X items)."""
+
+    def __init__(self, primal_clf, primal_extractor, dual_clf, dual_extractor, primal_cfg, dual_cfg,
+                 primal_learn_edge_att, dual_learn_edge_att):
+        super().__init__()
+        self.primal_clf, self.primal_extractor, self.dual_clf, self.dual_extractor = primal_clf, primal_extractor, dual_clf, dual_extractor
+        self.pc, self.dc = primal_cfg, dual_cfg
+        self.primal_learn_edge_att, self.dual_learn_edge_att = primal_learn_edge_att, dual_learn_edge_att
+        self.crit = Criterion(2, False)
+
+    def _edge_att(self, att, data, learn_edge_att):
+        N = data.x.shape[0]
+        if learn_edge_att:
+            if bk.is_undirected(data.edge_index, N):
+                return ops.symmetrise(att, torch.from_numpy(bk.reverse_edge_perm(data.edge_index, N)))
+            return att
+        return ops.lift_node_att_to_edge_att(att, data.edge_index)
+
+    def dual_forward_pass(self, primal_data, dual_data, epoch, training, primal_u=None, dual_U=None, primal_masks=None, dual_masks=None):
+        pemb = self.primal_clf.get_emb(primal_data.x, primal_data.edge_index, batch=primal_data.batch, edge_attr=primal_data.edge_attr)   # :191
+        plog = self.primal_extractor(pemb, primal_data.edge_index, primal_data.batch, masks=primal_masks)                                  # :199
+        patt = ops.concrete_sample(plog, primal_u, training)                                                                               # :204
+        demb = self.dual_clf.get_emb(dual_data.x, dual_data.edge_index, batch=dual_data.batch, edge_attr=dual_data.edge_attr)             # :208
+        dlog = self.dual_extractor(demb, dual_data.edge_index, dual_data.batch, masks=dual_masks)                                          # :209
+        datt = ops.gumbel_sigmoid(dlog, dual_U, tau=0.1) if training else (dlog / 0.1).sigmoid()                                            # :222
+        f1 = f1_sparsity_loss(datt, primal_data.edge_label.float())                                                                         # :226
+        dual_edge_att = self._edge_att(datt, dual_data, self.dual_learn_edge_att)
+        primal_edge_att = self._edge_att(patt, primal_data, self.primal_learn_edge_att)
+        if epoch > 50:
+            primal_edge_att = 0.3 * datt + (1 - 0.3) * primal_edge_att                                                                      # :253
+        plogits = self.primal_clf(primal_data.x, primal_data.edge_index, primal_data.batch, edge_attr=primal_data.edge_attr, edge_atten=primal_edge_att)
+        dlogits = self.dual_clf(dual_data.x, dual_data.edge_index, dual_data.batch, edge_attr=dual_data.edge_attr, edge_atten=dual_edge_att)
+        ppred = self.crit(plogits, primal_data.y) * self.pc["pred_loss_coef"]
+        dpred = self.crit(dlogits, dual_data.y) * self.dc["pred_loss_coef"]
+        dual_r = self.dc.get("fix_r") or ops.get_r(self.dc["decay_interval"], self.dc["decay_r"], epoch, final_r=self.dc.get("final_r", 0.1), init_r=self.dc.get("init_r", 0.9))
+        dinfo = ops.info_loss(dual_edge_att, dual_r) * self.dc["info_loss_coef"]
+        pinfo = ops.info_loss(primal_edge_att, dlog.sigmoid().detach()) * self.pc["info_loss_coef"]                                         # :129-132
+        loss = ppred + dpred + pinfo + dinfo + f1
+        return primal_edge_att, loss, {"loss": (loss - f1).item(), "pred": dpred.item(), "info": dinfo.item()}, plogits

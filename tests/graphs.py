@@ -35,3 +35,25 @@ def shuffle_edges(ei, seed):
     g = torch.Generator().manual_seed(seed)
     perm = torch.randperm(ei.shape[1], generator=g)
     return ei[:, perm].contiguous()
+
+
+def line_graph(ei, batch):
+    """Dual graph with one node per DIRECTED primal edge (as mutag_dual: N_dual = E_primal); two dual nodes are joined
+    (both directions) when their primal edges share an endpoint and are not the same undirected edge."""
+    import itertools
+    src, dst = ei[0].tolist(), ei[1].tolist()
+    E = len(src)
+    inc = {}
+    for k in range(E):
+        inc.setdefault(src[k], []).append(k)
+        inc.setdefault(dst[k], []).append(k)
+    es = set()
+    for _, ks in inc.items():
+        for a, b in itertools.combinations(sorted(set(ks)), 2):
+            if {src[a], dst[a]} != {src[b], dst[b]}:
+                es.add((a, b)); es.add((b, a))
+    es = sorted(es)
+    dei = torch.tensor([[a for a, _ in es], [b for _, b in es]], dtype=torch.int64).reshape(2, -1)
+    dbatch = batch[ei[0]].clone()
+    assert bool((dbatch[:-1] <= dbatch[1:]).all())
+    return dei, dbatch
