@@ -33,6 +33,8 @@ SIGNATURES = {
     "gsat_aggr_sum_bwd": (INT, [P, P, P, P, P, P, P, I64, I64, I64, F32, P, P, P, P, P, P]),
     "gsat_pna_fwd": (INT, [P, P, P, P, P, P, I64, I64, P, INT, P, INT, F32, F32, P, P]),
     "gsat_pna_bwd": (INT, [P, P, P, P, P, P, P, I64, I64, P, INT, P, INT, F32, F32, P, P, P, P, P]),
+    "gsat_embsum_fwd": (INT, [P, P, INT, P, I64, I64, P, P]),
+    "gsat_onehot_rows": (INT, [P, P, INT, I64, I64, P, P]),
     "gsat_gemm_workspace_floats": (SZ, [INT, I64, I64, I64]),
     "gsat_gemm_f32": (INT, [INT, INT, I64, I64, I64, P, I64, P, I64, P, I64, P, INT, P, SZ, P]),
     "gsat_attn_fwd_workspace_bytes": (SZ, [P]),

@@ -5,45 +5,45 @@ import torch
 import torch.nn as nn
 
 from .graph_index import get_index
-from .ops import segment_pool
+from .ops import EmbeddingSum, segment_pool
 
 # [3P] ogb 1.3.2 get_atom_feature_dims() / get_bond_feature_dims()
 ATOM_FEATURE_DIMS = [119, 5, 12, 12, 10, 6, 6, 2, 2]
 BOND_FEATURE_DIMS = [5, 6, 2]
 
 
-class AtomEncoder(nn.Module):
-    """sum of 9 per-column embeddings; keys ``atom_embedding_list.{i}.weight`` as ogb's (src/models/gin.py:23)."""
+class _CategoricalEncoder(nn.Module):
+    """Sum of per-column embeddings.  The ``nn.Embedding`` tables keep ogb's names (state_dict keys
+    ``atom_embedding_list.{i}.weight`` / ``bond_embedding_list.{i}.weight``); the lookup-sum and its backward run in
+    libgsat_hip (gather forward, one-hot MFMA GEMM backward)."""
+    _list_name = ""
+    _dims = ()
 
     def __init__(self, emb_dim):
         super().__init__()
-        self.atom_embedding_list = nn.ModuleList()
-        for dim in ATOM_FEATURE_DIMS:
+        tables = nn.ModuleList()
+        for dim in self._dims:
             emb = nn.Embedding(dim, emb_dim)
             nn.init.xavier_uniform_(emb.weight.data)
-            self.atom_embedding_list.append(emb)
+            tables.append(emb)
+        setattr(self, self._list_name, tables)
+        self._cache = {}
 
     def forward(self, x):
-        out = self.atom_embedding_list[0](x[:, 0])
-        for i in range(1, x.shape[1]):
-            out = out + self.atom_embedding_list[i](x[:, i])
-        return out
+        tables = getattr(self, self._list_name)
+        ncol = x.shape[1]
+        W_all = torch.cat([tables[i].weight for i in range(ncol)], dim=0)
+        return EmbeddingSum.apply(x, W_all, [tables[i].num_embeddings for i in range(ncol)], self._cache)
 
 
-class BondEncoder(nn.Module):
-    def __init__(self, emb_dim):
-        super().__init__()
-        self.bond_embedding_list = nn.ModuleList()
-        for dim in BOND_FEATURE_DIMS:
-            emb = nn.Embedding(dim, emb_dim)
-            nn.init.xavier_uniform_(emb.weight.data)
-            self.bond_embedding_list.append(emb)
+class AtomEncoder(_CategoricalEncoder):
+    """ogb AtomEncoder (src/models/gin.py:23)."""
+    _list_name, _dims = "atom_embedding_list", tuple(ATOM_FEATURE_DIMS)
 
-    def forward(self, edge_attr):
-        out = self.bond_embedding_list[0](edge_attr[:, 0])
-        for i in range(1, edge_attr.shape[1]):
-            out = out + self.bond_embedding_list[i](edge_attr[:, i])
-        return out
+
+class BondEncoder(_CategoricalEncoder):
+    """ogb BondEncoder (src/models/gin.py:25)."""
+    _list_name, _dims = "bond_embedding_list", tuple(BOND_FEATURE_DIMS)
 
 
 class BatchNorm(nn.Module):

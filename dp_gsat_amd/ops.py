@@ -400,3 +400,42 @@ class InstanceNormFn(torch.autograd.Function):
         call("gsat_instance_norm_bwd", ptr(y), ptr(dy), ptr(stats), ptr(seg_ptr), ptr(seg_order if ctx.has_order else None),
              ptr(row_seg), M, ctx.G, C, ptr(dx), ptr(ws), stream())
         return dx, None, None, None, None
+
+
+class EmbeddingSum(torch.autograd.Function):
+    """out = sum_col W[offset(col) + x[:, col]]  (ogb AtomEncoder / BondEncoder); backward = O^T dout (one MFMA GEMM)."""
+
+    @staticmethod
+    def forward(ctx, x_idx, W_all, dims, onehot_cache):
+        import ctypes
+        W = _f32c(W_all)
+        x_idx = x_idx.contiguous()
+        if x_idx.dtype != torch.int64 or x_idx.dim() != 2 or x_idx.shape[1] != len(dims):
+            raise ValueError("categorical features must be int64 [N, %d]" % len(dims))
+        N, H = x_idx.shape[0], W.shape[1]
+        d_arr = (ctypes.c_int32 * len(dims))(*dims)
+        out = torch.empty(N, H, dtype=torch.float32, device=W.device)
+        call("gsat_embsum_fwd", ptr(x_idx), d_arr, len(dims), ptr(W), N, H, ptr(out), stream())
+        ctx.x_idx, ctx.dims, ctx.cache, ctx.R = x_idx, tuple(dims), onehot_cache, W.shape[0]
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        import ctypes
+        from ._lib import load
+        dout = _f32c(dout)
+        x_idx, dims, R = ctx.x_idx, ctx.dims, ctx.R
+        N, H = dout.shape
+        Rp = (R + 3) // 4 * 4
+        key = (x_idx.data_ptr(), x_idx._version, N)
+        O = ctx.cache.get("O") if ctx.cache.get("key") == key else None
+        if O is None:
+            d_arr = (ctypes.c_int32 * len(dims))(*dims)
+            O = torch.empty(N, Rp, dtype=torch.float32, device=dout.device)
+            call("gsat_onehot_rows", ptr(x_idx), d_arr, len(dims), N, Rp, ptr(O), stream())
+            ctx.cache["key"], ctx.cache["O"], ctx.cache["x"] = key, O, x_idx
+        dW = torch.empty(Rp, H, dtype=torch.float32, device=dout.device)
+        wsf = int(load().gsat_gemm_workspace_floats(1, Rp, H, N))
+        ws = torch.empty(max(wsf, 1), dtype=torch.float32, device=dout.device)
+        call("gsat_gemm_f32", 1, 0, Rp, H, N, ptr(O), Rp, ptr(dout), H, ptr(dW), H, None, 0, ptr(ws), wsf, stream())
+        return None, dW[:R], None, None

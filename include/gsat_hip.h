@@ -176,6 +176,23 @@ int gsat_pna_bwd(const float* x, const float* att, const float* edge_emb, const 
                  float avg_deg_lin, float avg_deg_log, float* dx_self, float* dmsg, float* datt,
                  float* dedge_emb, void* stream);
 
+/* =============================== categorical encoders (ogb) ================================= */
+
+/*
+ * out[n,:] = sum_col W[offset(col) + x[n,col], :],  offset(col) = dims[0] + ... + dims[col-1]
+ * replaces: ogb AtomEncoder / BondEncoder forward (src/models/gin.py:22-25,45-47; src/models/pna.py:19-22,53-55).
+ * x: int64 [N,ncol]; dims: HOST int32[ncol] table sizes; W: the ncol tables concatenated [sum(dims), H].
+ * Out-of-range categories are clamped into their table.
+ */
+int gsat_embsum_fwd(const int64_t* x, const int32_t* dims, int ncol, const float* W, int64_t N, int64_t H,
+                    float* out, void* stream);
+/*
+ * One-hot matrix O [N, R_padded] (R_padded >= sum(dims), multiple of 4): O[n, offset(col)+x[n,col]] = 1.
+ * The encoder backward is dW = O^T dout (gsat_gemm_f32 with a_t = 1) instead of a sorted scatter-add.
+ */
+int gsat_onehot_rows(const int64_t* x, const int32_t* dims, int ncol, int64_t N, int64_t R_padded, float* O,
+                     void* stream);
+
 /* ================================ dense fp32 MFMA GEMM ======================================== */
 
 /*

@@ -166,3 +166,25 @@ def test_deterministic_bitwise(dev):
     assert len(outs[0]) == len(outs[1]) > 10
     for a, b in zip(*outs):
         assert torch.equal(a, b)
+
+
+def test_atom_bond_encoders(dev):
+    """ogb AtomEncoder / BondEncoder: gather forward, one-hot GEMM backward vs nn.Embedding sums."""
+    import dp_gsat_amd as G
+    from dp_gsat_amd.encoders import AtomEncoder, BondEncoder, ATOM_FEATURE_DIMS, BOND_FEATURE_DIMS
+    g = torch.Generator().manual_seed(0)
+    for Enc, OEnc, dims, n in ((AtomEncoder, om.AtomEncoder, ATOM_FEATURE_DIMS, 5000), (BondEncoder, om.BondEncoder, BOND_FEATURE_DIMS, 777)):
+        H = 80
+        x = torch.stack([torch.randint(0, d, (n,), generator=g) for d in dims], dim=1)
+        go = torch.randn(n, H, generator=g)
+        oe = OEnc(H)
+        oo = oe(x); oo.backward(go)
+        e = Enc(H).to(dev); e.load_state_dict(oe.state_dict())
+        assert list(e.state_dict()) == list(oe.state_dict())
+        xd = x.to(dev)
+        out = e(xd); out.backward(go.to(dev))
+        close(out, oo, 1e-5)
+        for (k, p), (_, q) in zip(e.named_parameters(), oe.named_parameters()):
+            close(p.grad, q.grad, what=k)
+        out2 = e(xd); out2.backward(go.to(dev))           # second step reuses the cached one-hot matrix
+        close(list(e.parameters())[0].grad, 2 * list(oe.parameters())[0].grad)
