@@ -1,0 +1,222 @@
+// BatchNorm1d over node rows (GIN `nn.1`, PNA `batch_norms.{i}` -- src/models/gin.py:58, src/models/pna.py:45,57),
+// training and eval, with an optional fused ReLU (PNA: relu(batch_norm(conv(...)))).
+// Statistics are two-pass (mean, then variance of the centred values) with two-stage, fixed-order column sums, so
+// results are bitwise reproducible; running statistics follow torch (momentum update, unbiased running_var).
+#include "common.h"
+
+namespace gsat {
+
+constexpr int NB = 256, NL = 16, NS = 16;     // 16 row slots x 16 lanes (float4) = 64 channels per block
+
+__device__ __forceinline__ float4 nslot_reduce(float4 v, float4 (*sm)[NL], int slot, int lane) {
+    __syncthreads();
+    sm[slot][lane] = v;
+    __syncthreads();
+    float4 r = f4zero();
+    if (slot == 0) {
+#pragma unroll
+        for (int s = 0; s < NS; ++s) { float4 t = sm[s][lane]; r.x += t.x; r.y += t.y; r.z += t.z; r.w += t.w; }
+    }
+    return r;
+}
+
+// column sum of a [RB, C] partial array, in row order
+__device__ __forceinline__ float4 colsum_part(const float* __restrict__ part, int RB, int C, int c) {
+    float4 a = f4zero();
+    for (int r = 0; r < RB; ++r) { float4 t = ld4(part + (size_t)r * C + c); a.x += t.x; a.y += t.y; a.z += t.z; a.w += t.w; }
+    return a;
+}
+
+// MODE 0: part[rb,c] = sum_rows x ; MODE 1: sum_rows (x - mean)^2 with mean = colsum(part0)/N
+template <int MODE>
+__global__ __launch_bounds__(NB) void k_bn_partial(const float* __restrict__ x, int64_t N, int C, int64_t rows_per_block,
+                                                   const float* __restrict__ part0, int RB0, float* __restrict__ part) {
+    __shared__ float4 sm[NS][NL];
+    const int lane = threadIdx.x % NL, slot = threadIdx.x / NL;
+    const int c = (blockIdx.x * NL + lane) * 4;
+    const bool on = c < C;
+    const int64_t beg = (int64_t)blockIdx.y * rows_per_block, end = min(N, beg + rows_per_block);
+    float4 mu = f4zero();
+    if (MODE == 1 && on) { float4 s = colsum_part(part0, RB0, C, c); const float inv = 1.f / (float)N; mu = make_float4(s.x * inv, s.y * inv, s.z * inv, s.w * inv); }
+    float4 acc = f4zero();
+    if (on)
+        for (int64_t r = beg + slot; r < end; r += NS) {
+            float4 v = ld4(x + (size_t)r * C + c);
+            if (MODE == 0) { acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w; }
+            else {
+                float a = v.x - mu.x, b = v.y - mu.y, d = v.z - mu.z, e = v.w - mu.w;
+                acc.x = fmaf(a, a, acc.x); acc.y = fmaf(b, b, acc.y); acc.z = fmaf(d, d, acc.z); acc.w = fmaf(e, e, acc.w);
+            }
+        }
+    float4 t = nslot_reduce(acc, sm, slot, lane);
+    if (slot == 0 && on) st4(part + (size_t)blockIdx.y * C + c, t);
+}
+
+__global__ void k_bn_finalize(const float* __restrict__ part0, const float* __restrict__ part1, int RB, int64_t N, int C, float eps,
+                              float momentum, float* __restrict__ mean, float* __restrict__ rstd, float* __restrict__ running_mean,
+                              float* __restrict__ running_var) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    float s = 0.f, q = 0.f;
+    for (int r = 0; r < RB; ++r) { s += part0[(size_t)r * C + c]; q += part1[(size_t)r * C + c]; }
+    const float m = s / (float)N, var = q / (float)N;
+    mean[c] = m;
+    rstd[c] = 1.f / sqrtf(var + eps);
+    if (running_mean) {
+        running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * m;
+        running_var[c] = (1.f - momentum) * running_var[c] + momentum * (N > 1 ? q / (float)(N - 1) : var);
+    }
+}
+
+__global__ void k_bn_eval_stats(const float* __restrict__ running_mean, const float* __restrict__ running_var, int C, float eps,
+                                float* __restrict__ mean, float* __restrict__ rstd) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c < C) { mean[c] = running_mean[c]; rstd[c] = 1.f / sqrtf(running_var[c] + eps); }
+}
+
+__global__ void k_bn_apply(const float* __restrict__ x, const float* __restrict__ mean, const float* __restrict__ rstd,
+                           const float* __restrict__ gamma, const float* __restrict__ beta, int64_t N, int C, int relu, float* __restrict__ y) {
+    const int C4 = C >> 2;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < N * C4; i += (int64_t)gridDim.x * blockDim.x) {
+        const int c = (int)(i % C4) * 4;
+        float4 v = ld4(x + i * 4), mu = ld4(mean + c), rs = ld4(rstd + c), g = ld4(gamma + c), b = ld4(beta + c);
+        float4 o = make_float4(fmaf((v.x - mu.x) * rs.x, g.x, b.x), fmaf((v.y - mu.y) * rs.y, g.y, b.y),
+                               fmaf((v.z - mu.z) * rs.z, g.z, b.z), fmaf((v.w - mu.w) * rs.w, g.w, b.w));
+        if (relu) o = make_float4(fmaxf(o.x, 0.f), fmaxf(o.y, 0.f), fmaxf(o.z, 0.f), fmaxf(o.w, 0.f));
+        st4(y + i * 4, o);
+    }
+}
+
+// backward partial sums: part[rb, 0:C] = sum dy' , part[rb, C:2C] = sum dy' * xhat ; dy' = dy * [y > 0] when relu
+__global__ __launch_bounds__(NB) void k_bn_bwd_partial(const float* __restrict__ x, const float* __restrict__ dy, const float* __restrict__ mean,
+                                                       const float* __restrict__ rstd, const float* __restrict__ gamma,
+                                                       const float* __restrict__ beta, int64_t N, int C, int relu, int64_t rows_per_block,
+                                                       float* __restrict__ part) {
+    __shared__ float4 sm[NS][NL];
+    const int lane = threadIdx.x % NL, slot = threadIdx.x / NL;
+    const int c = (blockIdx.x * NL + lane) * 4;
+    const bool on = c < C;
+    const int64_t beg = (int64_t)blockIdx.y * rows_per_block, end = min(N, beg + rows_per_block);
+    float4 a1 = f4zero(), a2 = f4zero();
+    if (on) {
+        const float4 mu = ld4(mean + c), rs = ld4(rstd + c), g = ld4(gamma + c), b = ld4(beta + c);
+        for (int64_t r = beg + slot; r < end; r += NS) {
+            float4 v = ld4(x + (size_t)r * C + c), d = ld4(dy + (size_t)r * C + c);
+            float4 xh = make_float4((v.x - mu.x) * rs.x, (v.y - mu.y) * rs.y, (v.z - mu.z) * rs.z, (v.w - mu.w) * rs.w);
+            if (relu) {
+                d.x = fmaf(xh.x, g.x, b.x) > 0.f ? d.x : 0.f; d.y = fmaf(xh.y, g.y, b.y) > 0.f ? d.y : 0.f;
+                d.z = fmaf(xh.z, g.z, b.z) > 0.f ? d.z : 0.f; d.w = fmaf(xh.w, g.w, b.w) > 0.f ? d.w : 0.f;
+            }
+            a1.x += d.x; a1.y += d.y; a1.z += d.z; a1.w += d.w;
+            a2.x = fmaf(d.x, xh.x, a2.x); a2.y = fmaf(d.y, xh.y, a2.y); a2.z = fmaf(d.z, xh.z, a2.z); a2.w = fmaf(d.w, xh.w, a2.w);
+        }
+    }
+    float4 t1 = nslot_reduce(a1, sm, slot, lane);
+    float4 t2 = nslot_reduce(a2, sm, slot, lane);
+    if (slot == 0 && on) {
+        st4(part + (size_t)blockIdx.y * 2 * C + c, t1);
+        st4(part + (size_t)blockIdx.y * 2 * C + C + c, t2);
+    }
+}
+
+__global__ void k_bn_bwd_finalize(const float* __restrict__ part, int RB, int C, float* __restrict__ dbeta, float* __restrict__ dgamma) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    float s1 = 0.f, s2 = 0.f;
+    for (int r = 0; r < RB; ++r) { s1 += part[(size_t)r * 2 * C + c]; s2 += part[(size_t)r * 2 * C + C + c]; }
+    dbeta[c] = s1; dgamma[c] = s2;
+}
+
+// training: dx = gamma*rstd*(dy' - dbeta/N - xhat*dgamma/N) ; eval: dx = gamma*rstd*dy'
+__global__ void k_bn_bwd_apply(const float* __restrict__ x, const float* __restrict__ dy, const float* __restrict__ mean,
+                               const float* __restrict__ rstd, const float* __restrict__ gamma, const float* __restrict__ beta,
+                               const float* __restrict__ dbeta, const float* __restrict__ dgamma, int64_t N, int C, int relu, int training,
+                               float* __restrict__ dx) {
+    const int C4 = C >> 2;
+    const float inv_n = 1.f / (float)N;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < N * C4; i += (int64_t)gridDim.x * blockDim.x) {
+        const int c = (int)(i % C4) * 4;
+        float4 v = ld4(x + i * 4), d = ld4(dy + i * 4), mu = ld4(mean + c), rs = ld4(rstd + c), g = ld4(gamma + c), b = ld4(beta + c);
+        float4 xh = make_float4((v.x - mu.x) * rs.x, (v.y - mu.y) * rs.y, (v.z - mu.z) * rs.z, (v.w - mu.w) * rs.w);
+        if (relu) {
+            d.x = fmaf(xh.x, g.x, b.x) > 0.f ? d.x : 0.f; d.y = fmaf(xh.y, g.y, b.y) > 0.f ? d.y : 0.f;
+            d.z = fmaf(xh.z, g.z, b.z) > 0.f ? d.z : 0.f; d.w = fmaf(xh.w, g.w, b.w) > 0.f ? d.w : 0.f;
+        }
+        float4 o;
+        if (training) {
+            float4 db = ld4(dbeta + c), dg = ld4(dgamma + c);
+            o = make_float4(g.x * rs.x * (d.x - db.x * inv_n - xh.x * dg.x * inv_n), g.y * rs.y * (d.y - db.y * inv_n - xh.y * dg.y * inv_n),
+                            g.z * rs.z * (d.z - db.z * inv_n - xh.z * dg.z * inv_n), g.w * rs.w * (d.w - db.w * inv_n - xh.w * dg.w * inv_n));
+        } else {
+            o = make_float4(g.x * rs.x * d.x, g.y * rs.y * d.y, g.z * rs.z * d.z, g.w * rs.w * d.w);
+        }
+        st4(dx + i * 4, o);
+    }
+}
+
+static inline void row_blocks(int64_t N, int64_t* RB, int64_t* rpb) {
+    int64_t rb = std::min<int64_t>(256, std::max<int64_t>(1, ceil_div(N, 64)));
+    *rpb = ceil_div(N, rb);
+    *RB = ceil_div(N, *rpb);
+}
+static inline int ew_grid(int64_t items) { return (int)std::max<int64_t>(1, std::min<int64_t>(ceil_div(items, 256), 256 * 32)); }
+
+}  // namespace gsat
+
+using namespace gsat;
+
+extern "C" {
+
+size_t gsat_bn_workspace_floats(int64_t N, int64_t C) {
+    int64_t RB, rpb;
+    row_blocks(N > 0 ? N : 1, &RB, &rpb);
+    return (size_t)RB * (size_t)C * 2;
+}
+
+int gsat_bn_fwd(const float* x, const float* gamma, const float* beta, float* running_mean, float* running_var, int64_t N, int64_t C,
+                int training, float momentum, float eps, int relu, float* y, float* save_mean, float* save_rstd, float* workspace,
+                void* stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    GSAT_REQUIRE(N >= 0 && C > 0 && C % 4 == 0 && N < (1ll << 31), GSAT_ERR_UNSUPPORTED, "gsat_bn_fwd: C must be a positive multiple of 4");
+    if (N == 0) return GSAT_OK;
+    GSAT_REQUIRE(x && gamma && beta && y && save_mean && save_rstd, GSAT_ERR_ARG, "gsat_bn_fwd: null pointer");
+    if (training) {
+        GSAT_REQUIRE(workspace, GSAT_ERR_WORKSPACE, "gsat_bn_fwd: workspace required in training mode");
+        int64_t RB, rpb;
+        row_blocks(N, &RB, &rpb);
+        float* part0 = workspace;
+        float* part1 = workspace + (size_t)RB * C;
+        const dim3 grid((unsigned)ceil_div(C, 64), (unsigned)RB);
+        k_bn_partial<0><<<grid, NB, 0, stream>>>(x, N, (int)C, rpb, nullptr, 0, part0);
+        k_bn_partial<1><<<grid, NB, 0, stream>>>(x, N, (int)C, rpb, part0, (int)RB, part1);
+        k_bn_finalize<<<(unsigned)ceil_div(C, 256), 256, 0, stream>>>(part0, part1, (int)RB, N, (int)C, eps, momentum, save_mean, save_rstd, running_mean, running_var);
+    } else {
+        GSAT_REQUIRE(running_mean && running_var, GSAT_ERR_ARG, "gsat_bn_fwd: eval mode needs running statistics");
+        k_bn_eval_stats<<<(unsigned)ceil_div(C, 256), 256, 0, stream>>>(running_mean, running_var, (int)C, eps, save_mean, save_rstd);
+    }
+    k_bn_apply<<<ew_grid(N * (C / 4)), 256, 0, stream>>>(x, save_mean, save_rstd, gamma, beta, N, (int)C, relu, y);
+    GSAT_LAUNCH_CHECK();
+    return GSAT_OK;
+}
+
+int gsat_bn_bwd(const float* x, const float* dy, const float* gamma, const float* beta, const float* save_mean, const float* save_rstd,
+                int64_t N, int64_t C, int training, int relu, float* dx, float* dgamma, float* dbeta, float* workspace, void* stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    GSAT_REQUIRE(N >= 0 && C > 0 && C % 4 == 0 && N < (1ll << 31), GSAT_ERR_UNSUPPORTED, "gsat_bn_bwd: C must be a positive multiple of 4");
+    GSAT_REQUIRE(dgamma && dbeta, GSAT_ERR_ARG, "gsat_bn_bwd: null gradient output");
+    if (N == 0) {
+        GSAT_CHECK_HIP(hipMemsetAsync(dgamma, 0, sizeof(float) * C, stream));
+        GSAT_CHECK_HIP(hipMemsetAsync(dbeta, 0, sizeof(float) * C, stream));
+        return GSAT_OK;
+    }
+    GSAT_REQUIRE(x && dy && gamma && beta && save_mean && save_rstd && dx && workspace, GSAT_ERR_ARG, "gsat_bn_bwd: null pointer");
+    int64_t RB, rpb;
+    row_blocks(N, &RB, &rpb);
+    k_bn_bwd_partial<<<dim3((unsigned)ceil_div(C, 64), (unsigned)RB), NB, 0, stream>>>(x, dy, save_mean, save_rstd, gamma, beta, N, (int)C, relu, rpb, workspace);
+    k_bn_bwd_finalize<<<(unsigned)ceil_div(C, 256), 256, 0, stream>>>(workspace, (int)RB, (int)C, dbeta, dgamma);
+    k_bn_bwd_apply<<<ew_grid(N * (C / 4)), 256, 0, stream>>>(x, dy, save_mean, save_rstd, gamma, beta, dbeta, dgamma, N, (int)C, relu, training, dx);
+    GSAT_LAUNCH_CHECK();
+    return GSAT_OK;
+}
+
+}  // extern "C"

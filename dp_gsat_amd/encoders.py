@@ -5,7 +5,7 @@ import torch
 import torch.nn as nn
 
 from .graph_index import get_index
-from .ops import EmbeddingSum, segment_pool
+from .ops import BatchNormFn, EmbeddingSum, segment_pool
 
 # [3P] ogb 1.3.2 get_atom_feature_dims() / get_bond_feature_dims()
 ATOM_FEATURE_DIMS = [119, 5, 12, 12, 10, 6, 6, 2, 2]
@@ -46,15 +46,33 @@ class BondEncoder(_CategoricalEncoder):
     _list_name, _dims = "bond_embedding_list", tuple(BOND_FEATURE_DIMS)
 
 
+class BatchNorm1d(nn.BatchNorm1d):
+    """nn.BatchNorm1d (same parameters / buffers / state_dict keys) whose arithmetic runs in libgsat_hip on ROCm tensors
+    with 2-D fp32 input; anything else (CPU tensors in the host-protocol tests, odd shapes) uses torch's implementation.
+    ``fused_relu`` applies ReLU inside the kernel (PNA)."""
+
+    def forward(self, x, fused_relu: bool = False):
+        hip_ok = (x.is_cuda and x.dim() == 2 and x.dtype == torch.float32 and self.affine and x.shape[1] % 4 == 0
+                  and (self.training or self.track_running_stats) and self.momentum is not None and x.shape[0] > 0)
+        if not hip_ok:
+            y = super().forward(x)
+            return torch.relu(y) if fused_relu else y
+        training = self.training or not self.track_running_stats
+        if self.training and self.track_running_stats and self.num_batches_tracked is not None:
+            self.num_batches_tracked.add_(1)
+        return BatchNormFn.apply(x, self.weight, self.bias, self.running_mean if self.track_running_stats else None,
+                                 self.running_var if self.track_running_stats else None, training, self.momentum, self.eps, fused_relu)
+
+
 class BatchNorm(nn.Module):
     """PyG's BatchNorm wrapper: keeps the BatchNorm1d as ``.module`` (keys ``batch_norms.{i}.module.*``)."""
 
     def __init__(self, in_channels):
         super().__init__()
-        self.module = nn.BatchNorm1d(in_channels)
+        self.module = BatchNorm1d(in_channels)
 
-    def forward(self, x):
-        return self.module(x)
+    def forward(self, x, fused_relu: bool = False):
+        return self.module(x, fused_relu)
 
 
 def _segments(batch, edge_index=None, num_nodes=None):

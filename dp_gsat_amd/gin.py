@@ -5,7 +5,7 @@ import torch.nn as nn
 import torch.nn.functional as F
 
 from .conv_layers import GINConv, GINEConv
-from .encoders import AtomEncoder, BondEncoder
+from .encoders import AtomEncoder, BatchNorm1d, BondEncoder
 from .graph_index import get_index
 from .ops import segment_pool
 
@@ -38,7 +38,7 @@ class GIN(nn.Module):
 
     @staticmethod
     def MLP(in_channels: int, out_channels: int):
-        return nn.Sequential(nn.Linear(in_channels, out_channels), nn.BatchNorm1d(out_channels),
+        return nn.Sequential(nn.Linear(in_channels, out_channels), BatchNorm1d(out_channels),
                              nn.ReLU(inplace=True), nn.Linear(out_channels, out_channels))
 
     def pool(self, x, batch, index):

@@ -439,3 +439,36 @@ class EmbeddingSum(torch.autograd.Function):
         ws = torch.empty(max(wsf, 1), dtype=torch.float32, device=dout.device)
         call("gsat_gemm_f32", 1, 0, Rp, H, N, ptr(O), Rp, ptr(dout), H, ptr(dW), H, None, 0, ptr(ws), wsf, stream())
         return None, dW[:R], None, None
+
+
+class BatchNormFn(torch.autograd.Function):
+    """BatchNorm1d over rows with optional fused ReLU (src/models/gin.py:58, src/models/pna.py:57)."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, running_mean, running_var, training, momentum, eps, relu):
+        from ._lib import load
+        x, weight, bias = _f32c(x), _f32c(weight), _f32c(bias)
+        N, C = x.shape
+        y = torch.empty_like(x)
+        mean = torch.empty(C, dtype=torch.float32, device=x.device)
+        rstd = torch.empty(C, dtype=torch.float32, device=x.device)
+        ws = torch.empty(max(int(load().gsat_bn_workspace_floats(N, C)), 1), dtype=torch.float32, device=x.device)
+        call("gsat_bn_fwd", ptr(x), ptr(weight), ptr(bias), ptr(running_mean), ptr(running_var), N, C, int(training),
+             float(momentum), float(eps), int(relu), ptr(y), ptr(mean), ptr(rstd), ptr(ws), stream())
+        ctx.save_for_backward(x, weight, bias, mean, rstd)
+        ctx.flags = (bool(training), bool(relu))
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        from ._lib import load
+        x, weight, bias, mean, rstd = ctx.saved_tensors
+        training, relu = ctx.flags
+        dy = _f32c(dy)
+        N, C = x.shape
+        dx = torch.empty_like(x)
+        dgamma, dbeta = torch.empty_like(weight), torch.empty_like(bias)
+        ws = torch.empty(max(int(load().gsat_bn_workspace_floats(N, C)), 1), dtype=torch.float32, device=x.device)
+        call("gsat_bn_bwd", ptr(x), ptr(dy), ptr(weight), ptr(bias), ptr(mean), ptr(rstd), N, C, int(training), int(relu),
+             ptr(dx), ptr(dgamma), ptr(dbeta), ptr(ws), stream())
+        return dx, dgamma, dbeta, None, None, None, None, None, None

@@ -52,7 +52,7 @@ class PNA(nn.Module):
         if edge_attr is not None:
             edge_attr = self.edge_encoder(edge_attr)
         for conv, batch_norm in zip(self.convs, self.batch_norms):
-            h = F.relu(batch_norm(conv(x, edge_index, edge_attr, edge_atten=edge_atten, index=index)))
+            h = batch_norm(conv(x, edge_index, edge_attr, edge_atten=edge_atten, index=index), fused_relu=True)   # relu(BN(.))
             x = h + x
             x = F.dropout(x, self.dropout_p, training=self.training)
         return x

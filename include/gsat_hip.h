@@ -176,6 +176,23 @@ int gsat_pna_bwd(const float* x, const float* att, const float* edge_emb, const 
                  float avg_deg_lin, float avg_deg_log, float* dx_self, float* dmsg, float* datt,
                  float* dedge_emb, void* stream);
 
+/* ================================ BatchNorm1d over node rows ================================= */
+
+/*
+ * y = [relu]( (x - mean) * rstd * gamma + beta ), per channel over the N rows.  training: batch statistics
+ * (two-pass mean / biased variance), running_mean / running_var updated in place with `momentum` (running_var
+ * takes the unbiased variance, as torch); eval: running statistics.  save_mean / save_rstd [C] feed the backward.
+ * replaces: nn.BatchNorm1d in GIN.MLP (src/models/gin.py:55-62) and PyG BatchNorm + F.relu in PNA
+ *           (src/models/pna.py:45,57).  workspace: gsat_bn_workspace_floats() floats.  C % 4 == 0.
+ */
+size_t gsat_bn_workspace_floats(int64_t N, int64_t C);
+int gsat_bn_fwd(const float* x, const float* gamma, const float* beta, float* running_mean, float* running_var,
+                int64_t N, int64_t C, int training, float momentum, float eps, int relu, float* y,
+                float* save_mean, float* save_rstd, float* workspace, void* stream);
+int gsat_bn_bwd(const float* x, const float* dy, const float* gamma, const float* beta, const float* save_mean,
+                const float* save_rstd, int64_t N, int64_t C, int training, int relu, float* dx, float* dgamma,
+                float* dbeta, float* workspace, void* stream);
+
 /* =============================== categorical encoders (ogb) ================================= */
 
 /*

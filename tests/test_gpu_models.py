@@ -188,3 +188,28 @@ def test_atom_bond_encoders(dev):
             close(p.grad, q.grad, what=k)
         out2 = e(xd); out2.backward(go.to(dev))           # second step reuses the cached one-hot matrix
         close(list(e.parameters())[0].grad, 2 * list(oe.parameters())[0].grad)
+
+
+@pytest.mark.parametrize("relu", [False, True])
+@pytest.mark.parametrize("training", [True, False])
+def test_batchnorm_kernels(dev, relu, training):
+    from dp_gsat_amd.encoders import BatchNorm1d
+    g = torch.Generator().manual_seed(3)
+    N, C = 3001, 80
+    x = torch.randn(N, C, generator=g) * 2 + 0.5
+    go = torch.randn(N, C, generator=g)
+    ref = torch.nn.BatchNorm1d(C)
+    with torch.no_grad():
+        ref.weight.uniform_(0.5, 1.5, generator=g); ref.bias.normal_(generator=g)
+        ref.running_mean.normal_(generator=g); ref.running_var.uniform_(0.5, 2.0, generator=g)
+    mine = BatchNorm1d(C).to(dev); mine.load_state_dict(ref.state_dict())
+    ref.train(training); mine.train(training)
+    xo = x.clone().requires_grad_(True)
+    yo = ref(xo); yo = torch.relu(yo) if relu else yo
+    yo.backward(go)
+    xd = x.to(dev).requires_grad_(True)
+    yd = mine(xd, fused_relu=relu); yd.backward(go.to(dev))
+    close(yd, yo); close(xd.grad, xo.grad)
+    close(mine.weight.grad, ref.weight.grad); close(mine.bias.grad, ref.bias.grad)
+    close(mine.running_mean, ref.running_mean, 1e-5); close(mine.running_var, ref.running_var, 1e-5)
+    assert int(mine.num_batches_tracked) == int(ref.num_batches_tracked)
