@@ -11,7 +11,7 @@ import torch
 import torch.nn as nn
 
 from .graph_index import get_index
-from .ops import masked_sum_aggregate, pna_aggregate
+from .ops import linear, masked_sum_aggregate, pna_aggregate
 
 
 def _index_of(edge_index, x, index):
@@ -76,7 +76,11 @@ class PNAConvSimple(nn.Module):
                             self.scalers, self.avg_deg)
         if agg.shape[1] != self.post_nn[0].in_features:
             raise ValueError(f"PNAConvSimple was built for F_in={self.F_in} but the message is {agg.shape[1]} wide")
-        return self.post_nn(agg)
+        lin0 = self.post_nn[0]                       # [N, A*S*F] x [A*S*F, H]: the widest GEMM of the backbone
+        out = linear(agg, lin0.weight, lin0.bias)
+        for layer in list(self.post_nn)[1:]:
+            out = layer(out)
+        return out
 
     def __repr__(self):
         return f"{self.__class__.__name__}({self.in_channels}, {self.out_channels})"

@@ -20,24 +20,24 @@ __device__ __forceinline__ float4 nslot_reduce(float4 v, float4 (*sm)[NL], int s
     return r;
 }
 
-// column sum of a [RB, C] partial array, in row order
-__device__ __forceinline__ float4 colsum_part(const float* __restrict__ part, int RB, int C, int c) {
+// column sum of a [RB, C] partial array by one block (16 row slots x 16 lanes), fixed order; valid in slot 0
+__device__ __forceinline__ float4 block_colsum(const float* __restrict__ part, int RB, int ld, int c, bool on, float4 (*sm)[NL], int slot, int lane) {
     float4 a = f4zero();
-    for (int r = 0; r < RB; ++r) { float4 t = ld4(part + (size_t)r * C + c); a.x += t.x; a.y += t.y; a.z += t.z; a.w += t.w; }
-    return a;
+    if (on)
+        for (int r = slot; r < RB; r += NS) { float4 t = ld4(part + (size_t)r * ld + c); a.x += t.x; a.y += t.y; a.z += t.z; a.w += t.w; }
+    return nslot_reduce(a, sm, slot, lane);
 }
 
-// MODE 0: part[rb,c] = sum_rows x ; MODE 1: sum_rows (x - mean)^2 with mean = colsum(part0)/N
+// MODE 0: part[rb,c] = sum_rows x ; MODE 1: sum_rows (x - mean)^2
 template <int MODE>
 __global__ __launch_bounds__(NB) void k_bn_partial(const float* __restrict__ x, int64_t N, int C, int64_t rows_per_block,
-                                                   const float* __restrict__ part0, int RB0, float* __restrict__ part) {
+                                                   const float* __restrict__ mean, float* __restrict__ part) {
     __shared__ float4 sm[NS][NL];
     const int lane = threadIdx.x % NL, slot = threadIdx.x / NL;
     const int c = (blockIdx.x * NL + lane) * 4;
     const bool on = c < C;
     const int64_t beg = (int64_t)blockIdx.y * rows_per_block, end = min(N, beg + rows_per_block);
-    float4 mu = f4zero();
-    if (MODE == 1 && on) { float4 s = colsum_part(part0, RB0, C, c); const float inv = 1.f / (float)N; mu = make_float4(s.x * inv, s.y * inv, s.z * inv, s.w * inv); }
+    const float4 mu = (MODE == 1 && on) ? ld4(mean + c) : f4zero();
     float4 acc = f4zero();
     if (on)
         for (int64_t r = beg + slot; r < end; r += NS) {
@@ -52,19 +52,30 @@ __global__ __launch_bounds__(NB) void k_bn_partial(const float* __restrict__ x, 
     if (slot == 0 && on) st4(part + (size_t)blockIdx.y * C + c, t);
 }
 
-__global__ void k_bn_finalize(const float* __restrict__ part0, const float* __restrict__ part1, int RB, int64_t N, int C, float eps,
-                              float momentum, float* __restrict__ mean, float* __restrict__ rstd, float* __restrict__ running_mean,
-                              float* __restrict__ running_var) {
-    const int c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= C) return;
-    float s = 0.f, q = 0.f;
-    for (int r = 0; r < RB; ++r) { s += part0[(size_t)r * C + c]; q += part1[(size_t)r * C + c]; }
-    const float m = s / (float)N, var = q / (float)N;
-    mean[c] = m;
-    rstd[c] = 1.f / sqrtf(var + eps);
-    if (running_mean) {
-        running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * m;
-        running_var[c] = (1.f - momentum) * running_var[c] + momentum * (N > 1 ? q / (float)(N - 1) : var);
+// STAGE 0: mean = colsum(part)/N ; STAGE 1: rstd = 1/sqrt(colsum(part)/N + eps) and the running-statistics update
+template <int STAGE>
+__global__ __launch_bounds__(NB) void k_bn_finalize(const float* __restrict__ part, int RB, int64_t N, int C, float eps, float momentum,
+                                                    float* __restrict__ mean, float* __restrict__ rstd, float* __restrict__ running_mean,
+                                                    float* __restrict__ running_var) {
+    __shared__ float4 sm[NS][NL];
+    const int lane = threadIdx.x % NL, slot = threadIdx.x / NL;
+    const int c = (blockIdx.x * NL + lane) * 4;
+    const bool on = c < C;
+    float4 t = block_colsum(part, RB, C, c, on, sm, slot, lane);
+    if (slot != 0 || !on) return;
+    const float inv = 1.f / (float)N;
+    if (STAGE == 0) {
+        st4(mean + c, make_float4(t.x * inv, t.y * inv, t.z * inv, t.w * inv));
+    } else {
+        st4(rstd + c, make_float4(1.f / sqrtf(t.x * inv + eps), 1.f / sqrtf(t.y * inv + eps), 1.f / sqrtf(t.z * inv + eps), 1.f / sqrtf(t.w * inv + eps)));
+        if (running_mean) {
+            const float ub = N > 1 ? 1.f / (float)(N - 1) : inv;
+            float4 m = ld4(mean + c), rm = ld4(running_mean + c), rv = ld4(running_var + c);
+            st4(running_mean + c, make_float4((1.f - momentum) * rm.x + momentum * m.x, (1.f - momentum) * rm.y + momentum * m.y,
+                                              (1.f - momentum) * rm.z + momentum * m.z, (1.f - momentum) * rm.w + momentum * m.w));
+            st4(running_var + c, make_float4((1.f - momentum) * rv.x + momentum * t.x * ub, (1.f - momentum) * rv.y + momentum * t.y * ub,
+                                             (1.f - momentum) * rv.z + momentum * t.z * ub, (1.f - momentum) * rv.w + momentum * t.w * ub));
+        }
     }
 }
 
@@ -119,12 +130,15 @@ __global__ __launch_bounds__(NB) void k_bn_bwd_partial(const float* __restrict__
     }
 }
 
-__global__ void k_bn_bwd_finalize(const float* __restrict__ part, int RB, int C, float* __restrict__ dbeta, float* __restrict__ dgamma) {
-    const int c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= C) return;
-    float s1 = 0.f, s2 = 0.f;
-    for (int r = 0; r < RB; ++r) { s1 += part[(size_t)r * 2 * C + c]; s2 += part[(size_t)r * 2 * C + C + c]; }
-    dbeta[c] = s1; dgamma[c] = s2;
+__global__ __launch_bounds__(NB) void k_bn_bwd_finalize(const float* __restrict__ part, int RB, int C, float* __restrict__ dbeta,
+                                                        float* __restrict__ dgamma) {
+    __shared__ float4 sm[NS][NL];
+    const int lane = threadIdx.x % NL, slot = threadIdx.x / NL;
+    const int c = (blockIdx.x * NL + lane) * 4;
+    const bool on = c < C;
+    float4 t1 = block_colsum(part, RB, 2 * C, c, on, sm, slot, lane);
+    float4 t2 = block_colsum(part + C, RB, 2 * C, c, on, sm, slot, lane);
+    if (slot == 0 && on) { st4(dbeta + c, t1); st4(dgamma + c, t2); }
 }
 
 // training: dx = gamma*rstd*(dy' - dbeta/N - xhat*dgamma/N) ; eval: dx = gamma*rstd*dy'
@@ -187,9 +201,11 @@ int gsat_bn_fwd(const float* x, const float* gamma, const float* beta, float* ru
         float* part0 = workspace;
         float* part1 = workspace + (size_t)RB * C;
         const dim3 grid((unsigned)ceil_div(C, 64), (unsigned)RB);
-        k_bn_partial<0><<<grid, NB, 0, stream>>>(x, N, (int)C, rpb, nullptr, 0, part0);
-        k_bn_partial<1><<<grid, NB, 0, stream>>>(x, N, (int)C, rpb, part0, (int)RB, part1);
-        k_bn_finalize<<<(unsigned)ceil_div(C, 256), 256, 0, stream>>>(part0, part1, (int)RB, N, (int)C, eps, momentum, save_mean, save_rstd, running_mean, running_var);
+        const unsigned ct = (unsigned)ceil_div(C, 64);
+        k_bn_partial<0><<<grid, NB, 0, stream>>>(x, N, (int)C, rpb, nullptr, part0);
+        k_bn_finalize<0><<<ct, NB, 0, stream>>>(part0, (int)RB, N, (int)C, eps, momentum, save_mean, save_rstd, running_mean, running_var);
+        k_bn_partial<1><<<grid, NB, 0, stream>>>(x, N, (int)C, rpb, save_mean, part1);
+        k_bn_finalize<1><<<ct, NB, 0, stream>>>(part1, (int)RB, N, (int)C, eps, momentum, save_mean, save_rstd, running_mean, running_var);
     } else {
         GSAT_REQUIRE(running_mean && running_var, GSAT_ERR_ARG, "gsat_bn_fwd: eval mode needs running statistics");
         k_bn_eval_stats<<<(unsigned)ceil_div(C, 256), 256, 0, stream>>>(running_mean, running_var, (int)C, eps, save_mean, save_rstd);
@@ -213,7 +229,7 @@ int gsat_bn_bwd(const float* x, const float* dy, const float* gamma, const float
     int64_t RB, rpb;
     row_blocks(N, &RB, &rpb);
     k_bn_bwd_partial<<<dim3((unsigned)ceil_div(C, 64), (unsigned)RB), NB, 0, stream>>>(x, dy, save_mean, save_rstd, gamma, beta, N, (int)C, relu, rpb, workspace);
-    k_bn_bwd_finalize<<<(unsigned)ceil_div(C, 256), 256, 0, stream>>>(workspace, (int)RB, (int)C, dbeta, dgamma);
+    k_bn_bwd_finalize<<<(unsigned)ceil_div(C, 64), NB, 0, stream>>>(workspace, (int)RB, (int)C, dbeta, dgamma);
     k_bn_bwd_apply<<<ew_grid(N * (C / 4)), 256, 0, stream>>>(x, dy, save_mean, save_rstd, gamma, beta, dbeta, dgamma, N, (int)C, relu, training, dx);
     GSAT_LAUNCH_CHECK();
     return GSAT_OK;
