@@ -11,7 +11,7 @@ import torch
 import torch.nn as nn
 
 from .graph_index import get_index
-from .ops import linear, masked_sum_aggregate, pna_aggregate
+from .ops import masked_sum_aggregate, pna_aggregate
 
 
 def _index_of(edge_index, x, index):
@@ -42,7 +42,8 @@ class GINEConv(nn.Module):
         self._eps0 = float(eps)
         if in_channels is None:
             in_channels = next(m for m in nn_.modules() if isinstance(m, nn.Linear)).in_features
-        self.lin = nn.Linear(edge_dim, in_channels) if edge_dim is not None else None
+        from .encoders import Linear
+        self.lin = Linear(edge_dim, in_channels) if edge_dim is not None else None
 
     def forward(self, x, edge_index, edge_attr=None, edge_atten=None, size=None, index=None):
         if self.lin is None and x.size(-1) != edge_attr.size(-1):
@@ -66,9 +67,10 @@ class PNAConvSimple(nn.Module):
         # statistics of the histogram VALUES, as the reference computes them (conv_layers.py:141-146)
         self.avg_deg: Dict[str, float] = {"lin": deg.mean().item(), "log": (deg + 1).log().mean().item(),
                                           "exp": deg.exp().mean().item()}
-        modules = [nn.Linear(len(aggregators) * len(scalers) * self.F_in, self.F_out)]
+        from .encoders import Linear
+        modules = [Linear(len(aggregators) * len(scalers) * self.F_in, self.F_out)]
         for _ in range(post_layers - 1):
-            modules += [nn.ReLU(), nn.Linear(self.F_out, self.F_out)]
+            modules += [nn.ReLU(), Linear(self.F_out, self.F_out)]
         self.post_nn = nn.Sequential(*modules)
 
     def forward(self, x, edge_index, edge_attr=None, edge_atten=None, index=None):
@@ -76,11 +78,7 @@ class PNAConvSimple(nn.Module):
                             self.scalers, self.avg_deg)
         if agg.shape[1] != self.post_nn[0].in_features:
             raise ValueError(f"PNAConvSimple was built for F_in={self.F_in} but the message is {agg.shape[1]} wide")
-        lin0 = self.post_nn[0]                       # [N, A*S*F] x [A*S*F, H]: the widest GEMM of the backbone
-        out = linear(agg, lin0.weight, lin0.bias)
-        for layer in list(self.post_nn)[1:]:
-            out = layer(out)
-        return out
+        return self.post_nn(agg)
 
     def __repr__(self):
         return f"{self.__class__.__name__}({self.in_channels}, {self.out_channels})"

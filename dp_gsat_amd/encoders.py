@@ -5,7 +5,7 @@ import torch
 import torch.nn as nn
 
 from .graph_index import get_index
-from .ops import BatchNormFn, EmbeddingSum, segment_pool
+from .ops import BatchNormFn, EmbeddingSum, linear, segment_pool
 
 # [3P] ogb 1.3.2 get_atom_feature_dims() / get_bond_feature_dims()
 ATOM_FEATURE_DIMS = [119, 5, 12, 12, 10, 6, 6, 2, 2]
@@ -44,6 +44,14 @@ class AtomEncoder(_CategoricalEncoder):
 class BondEncoder(_CategoricalEncoder):
     """ogb BondEncoder (src/models/gin.py:25)."""
     _list_name, _dims = "bond_embedding_list", tuple(BOND_FEATURE_DIMS)
+
+
+class Linear(nn.Linear):
+    """nn.Linear (same parameters / keys) for node- and edge-row inputs: forward and dx stay library GEMMs, the weight
+    gradient (a reduction over ~1e4..1e7 rows into a tiny matrix) uses the hand-written split-K MFMA GEMM."""
+
+    def forward(self, x):
+        return linear(x, self.weight, self.bias)
 
 
 class BatchNorm1d(nn.BatchNorm1d):

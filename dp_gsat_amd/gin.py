@@ -5,7 +5,7 @@ import torch.nn as nn
 import torch.nn.functional as F
 
 from .conv_layers import GINConv, GINEConv
-from .encoders import AtomEncoder, BatchNorm1d, BondEncoder
+from .encoders import AtomEncoder, BatchNorm1d, BondEncoder, Linear
 from .graph_index import get_index
 from .ops import segment_pool
 
@@ -24,9 +24,9 @@ class GIN(nn.Module):
             if with_edges:
                 self.edge_encoder = BondEncoder(emb_dim=hidden)
         else:
-            self.node_encoder = nn.Linear(x_dim, hidden)
+            self.node_encoder = Linear(x_dim, hidden)
             if with_edges:
-                self.edge_encoder = nn.Linear(edge_attr_dim, hidden)
+                self.edge_encoder = Linear(edge_attr_dim, hidden)
         self.convs = nn.ModuleList()
         self.relu = nn.ReLU()
         for _ in range(self.n_layers):
@@ -38,8 +38,8 @@ class GIN(nn.Module):
 
     @staticmethod
     def MLP(in_channels: int, out_channels: int):
-        return nn.Sequential(nn.Linear(in_channels, out_channels), BatchNorm1d(out_channels),
-                             nn.ReLU(inplace=True), nn.Linear(out_channels, out_channels))
+        return nn.Sequential(Linear(in_channels, out_channels), BatchNorm1d(out_channels),
+                             nn.ReLU(inplace=True), Linear(out_channels, out_channels))
 
     def pool(self, x, batch, index):
         return segment_pool(x, index.graphs(batch), mean=False)          # global_add_pool

@@ -475,33 +475,37 @@ class BatchNormFn(torch.autograd.Function):
 
 
 class LinearFn(torch.autograd.Function):
-    """y = x W^T + b for tall-skinny x: forward on the hand-written fp32 MFMA GEMM (bias in the epilogue); the two
-    backward products are plain library GEMMs (hipBLASLt via torch), which already run near their roofline here."""
+    """y = x W^T + b for tall-skinny x.  Forward and dx are plain library GEMMs (torch -> hipBLASLt, already near
+    roofline here); the weight gradient dW = dy^T x reduces over the ~1e5 node rows into a tiny [out, in] matrix, where
+    the library picks a non-split kernel (308 us at C3) -- it goes through the hand-written split-K MFMA GEMM."""
 
     @staticmethod
     def forward(ctx, x, weight, bias):
         x, weight = _f32c(x), _f32c(weight)
-        bias = None if bias is None else _f32c(bias)
-        M, K = x.shape
-        N = weight.shape[0]
-        y = torch.empty(M, N, dtype=torch.float32, device=x.device)
-        call("gsat_gemm_f32", 0, 1, M, N, K, ptr(x), K, ptr(weight), K, ptr(y), N, ptr(bias), 0, None, 0, stream())
+        y = torch.nn.functional.linear(x, weight, bias)
         ctx.save_for_backward(x, weight)
         ctx.has_bias = bias is not None
         return y
 
     @staticmethod
     def backward(ctx, dy):
+        from ._lib import load
         x, weight = ctx.saved_tensors
         dy = _f32c(dy)
         dx = dy @ weight if ctx.needs_input_grad[0] else None
-        dw = dy.t() @ x if ctx.needs_input_grad[1] else None
+        dw = None
+        if ctx.needs_input_grad[1]:
+            rows, n_out, n_in = x.shape[0], weight.shape[0], weight.shape[1]
+            dw = torch.empty_like(weight)
+            wsf = int(load().gsat_gemm_workspace_floats(1, n_out, n_in, rows))
+            ws = torch.empty(max(wsf, 1), dtype=torch.float32, device=x.device)
+            call("gsat_gemm_f32", 1, 0, n_out, n_in, rows, ptr(dy), n_out, ptr(x), n_in, ptr(dw), n_in, None, 0, ptr(ws), wsf, stream())
         db = dy.sum(0) if ctx.has_bias and ctx.needs_input_grad[2] else None
         return dx, dw, db
 
 
 def linear(x, weight, bias=None):
     """nn.functional.linear for 2-D fp32 ROCm inputs with 4-aligned widths; anything else goes to torch."""
-    if x.is_cuda and x.dim() == 2 and x.dtype == torch.float32 and x.shape[1] % 4 == 0 and x.shape[0] > 0:
+    if x.is_cuda and x.dim() == 2 and x.dtype == torch.float32 and x.shape[1] % 4 == 0 and weight.shape[0] % 4 == 0 and x.shape[0] > 0:
         return LinearFn.apply(x, weight, bias)
     return torch.nn.functional.linear(x, weight, bias)

@@ -5,7 +5,7 @@ import torch.nn as nn
 import torch.nn.functional as F
 
 from .conv_layers import PNAConvSimple
-from .encoders import AtomEncoder, BatchNorm, BondEncoder
+from .encoders import AtomEncoder, BatchNorm, BondEncoder, Linear
 from .graph_index import get_index
 from .ops import segment_pool
 
@@ -23,9 +23,9 @@ class PNA(nn.Module):
             if edge_attr_dim != 0 and use_edge_attr:
                 self.edge_encoder = BondEncoder(emb_dim=hidden)
         else:
-            self.node_encoder = nn.Linear(x_dim, hidden)
+            self.node_encoder = Linear(x_dim, hidden)
             if edge_attr_dim != 0 and use_edge_attr:
-                self.edge_encoder = nn.Linear(edge_attr_dim, hidden)
+                self.edge_encoder = Linear(edge_attr_dim, hidden)
         aggregators = model_config["aggregators"]
         scalers = ["identity", "amplification", "attenuation"] if model_config["scalers"] else ["identity"]
         deg = model_config["deg"]

@@ -18,3 +18,11 @@ def dev():
     if not torch.cuda.is_available():
         pytest.skip("no GPU")
     return torch.device("cuda:0")
+
+
+@pytest.fixture(autouse=True)
+def _seed_everything():
+    """Module parameters are drawn from torch's global generator: pin it so every test is reproducible."""
+    import torch
+    torch.manual_seed(1234)
+    yield
