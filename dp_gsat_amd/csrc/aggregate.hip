@@ -440,8 +440,8 @@ int aggr_sum_fwd_impl(hipStream_t stream, const float* x, const float* self_rows
     if (N == 0) return GSAT_OK;
     RowGeom g;
     GSAT_REQUIRE(row_geom(H, &g), GSAT_ERR_UNSUPPORTED, "gsat_aggr_sum_fwd: H=%lld must be a multiple of 4 and <= 2048", (long long)H);
-    GSAT_REQUIRE(x && rowptr && col && out, GSAT_ERR_ARG, "gsat_aggr_sum_fwd: null pointer");
-    GSAT_REQUIRE((att == nullptr && edge_emb == nullptr) || eid, GSAT_ERR_ARG, "gsat_aggr_sum_fwd: eid required with att/edge_emb");
+    GSAT_REQUIRE(x && rowptr && out && (col || E == 0), GSAT_ERR_ARG, "gsat_aggr_sum_fwd: null pointer");
+    GSAT_REQUIRE((att == nullptr && edge_emb == nullptr) || eid || E == 0, GSAT_ERR_ARG, "gsat_aggr_sum_fwd: eid required with att/edge_emb");
     GSAT_REQUIRE(chunk_ptr == nullptr || partial != nullptr, GSAT_ERR_ARG, "gsat_aggr_sum_fwd: chunk_ptr needs a partial-sum workspace");
     if (E <= CH) chunk_ptr = nullptr;                      // no row can be long
     if (!self_rows) self_rows = x;
@@ -487,7 +487,7 @@ int gsat_aggr_sum_bwd(const float* x, const float* att, const float* edge_emb, c
     if (N == 0) return GSAT_OK;
     RowGeom g;
     GSAT_REQUIRE(row_geom(H, &g), GSAT_ERR_UNSUPPORTED, "gsat_aggr_sum_bwd: H=%lld must be a multiple of 4 and <= 2048", (long long)H);
-    GSAT_REQUIRE(x && dout && rowptr_src && dst_sorted && eid_src && dx, GSAT_ERR_ARG, "gsat_aggr_sum_bwd: null pointer");
+    GSAT_REQUIRE(x && dout && rowptr_src && dx && ((dst_sorted && eid_src) || E == 0), GSAT_ERR_ARG, "gsat_aggr_sum_bwd: null pointer");
     GSAT_REQUIRE(chunk_ptr == nullptr || partial != nullptr, GSAT_ERR_ARG, "gsat_aggr_sum_bwd: chunk_ptr needs a partial-sum workspace");
     if (E <= CH) chunk_ptr = nullptr;
     int nb, rpg;

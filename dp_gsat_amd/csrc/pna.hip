@@ -386,7 +386,7 @@ int gsat_pna_fwd(const float* x, const float* att, const float* edge_emb, const 
     if (N == 0) return GSAT_OK;
     const int lpr = pna_lpr(H);
     GSAT_REQUIRE(lpr, GSAT_ERR_UNSUPPORTED, "gsat_pna_fwd: H=%lld must be a multiple of 4 and <= 256", (long long)H);
-    GSAT_REQUIRE(x && rowptr && col && out && eid, GSAT_ERR_ARG, "gsat_pna_fwd: null pointer");
+    GSAT_REQUIRE(x && rowptr && out, GSAT_ERR_ARG, "gsat_pna_fwd: null pointer");   /* col / eid may be NULL when E == 0 */
     int nb, rpg;
     pna_grid(N, lpr, &nb, &rpg);
 #define CALL(L)                                                                                                              \
@@ -412,7 +412,7 @@ int gsat_pna_bwd(const float* x, const float* att, const float* edge_emb, const 
     if (N == 0) return GSAT_OK;
     const int lpr = pna_lpr(H);
     GSAT_REQUIRE(lpr, GSAT_ERR_UNSUPPORTED, "gsat_pna_bwd: H=%lld must be a multiple of 4 and <= 256", (long long)H);
-    GSAT_REQUIRE(x && dout && rowptr && col && eid && dx_self && dmsg, GSAT_ERR_ARG, "gsat_pna_bwd: null pointer");
+    GSAT_REQUIRE(x && dout && rowptr && dx_self, GSAT_ERR_ARG, "gsat_pna_bwd: null pointer");   /* col / eid / dmsg may be NULL when E == 0 */
     int nb, rpg;
     pna_grid(N, lpr, &nb, &rpg);
 #define CALL(L)                                                                                                              \
