@@ -54,6 +54,9 @@ SIGNATURES = {
     "gsat_symmetrise": (INT, [P, P, I64, P, P]),
     "gsat_info_loss_fwd": (INT, [P, P, F32, I64, P, P, P]),
     "gsat_info_loss_bwd": (INT, [P, P, F32, P, I64, P, P]),
+    "gsat_collate": (INT, [P, I64, P, P, P, I64, P, P, I64, I64, P, P, P, P, P]),
+    "gsat_line_graph_pair_counts": (INT, [P, I64, P, P]),
+    "gsat_line_graph": (INT, [P, P, P, I64, I64, P, P]),
     "gsat_narrow_i64": (INT, [P, I64, P, P]),
     "gsat_segment_pool_fwd": (INT, [P, P, I64, I64, INT, P, P]),
     "gsat_segment_pool_bwd": (INT, [P, P, I64, I64, INT, P, P]),

@@ -11,7 +11,7 @@ import torch
 import torch.nn as nn
 
 from .graph_index import get_index
-from .ops import masked_sum_aggregate, pna_aggregate
+from .ops import MaskedSumAggregate, masked_sum_aggregate, pna_aggregate
 
 
 def _index_of(edge_index, x, index):
@@ -82,3 +82,30 @@ class PNAConvSimple(nn.Module):
 
     def __repr__(self):
         return f"{self.__class__.__name__}({self.in_channels}, {self.out_channels})"
+
+
+class LEConv(nn.Module):
+    """out_i = sum_j a_ji w_ji (lin1(x)_j - lin2(x)_i) + lin3(x)_i   (src/models/conv_layers.py:69-92; [3P] PyG LEConv:
+    lin1 / lin3 with bias, lin2 without).  The message sum splits into a masked gather-sum of lin1(x) and a per-row weight
+    total, so it reuses the GIN aggregation kernels; no [E,H] message is materialised."""
+
+    def __init__(self, in_channels: int, out_channels: int, bias: bool = True):
+        super().__init__()
+        from .encoders import Linear
+        self.in_channels, self.out_channels = in_channels, out_channels
+        self.lin1 = Linear(in_channels, out_channels, bias=bias)
+        self.lin2 = Linear(in_channels, out_channels, bias=False)
+        self.lin3 = Linear(in_channels, out_channels, bias=bias)
+
+    def forward(self, x, edge_index, edge_weight=None, edge_atten=None, index=None):
+        index = _index_of(edge_index, x, index)
+        a, b = self.lin1(x), self.lin2(x)
+        w = None
+        if edge_weight is not None:
+            w = edge_weight.view(-1, 1)
+        if edge_atten is not None:
+            w = edge_atten.view(-1, 1) if w is None else w * edge_atten.view(-1, 1)
+        agg = MaskedSumAggregate.apply(a, w, None, index, 0.0)                       # sum_j w_ji a_j
+        ones = torch.ones(x.shape[0], 4, dtype=x.dtype, device=x.device)
+        wsum = MaskedSumAggregate.apply(ones, w, None, index, 0.0)[:, :1]            # sum_j w_ji  (in-degree if w is None)
+        return agg - b * wsum + self.lin3(x)

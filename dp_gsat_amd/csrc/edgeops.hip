@@ -191,3 +191,140 @@ int gsat_narrow_i64(const int64_t* in, int64_t n, int32_t* out, void* stream_) {
 }
 
 }  // extern "C"
+
+// ------------------------------------------------------------------------------------------------
+// Device-side batch assembly (PyG Batch.from_data_list, src/utils/get_data_loaders.py:130-145): the dataset stays packed
+// in HBM (all graphs' nodes / edges concatenated, local node ids); a batch is a list of graph ids.
+// ------------------------------------------------------------------------------------------------
+namespace gsat {
+
+__device__ __forceinline__ int seg_of(const int64_t* __restrict__ ptr, int nseg, int64_t i) {   // ptr[s] <= i < ptr[s+1]
+    int lo = 0, hi = nseg;
+    while (hi - lo > 1) {
+        int mid = (lo + hi) >> 1;
+        if (ptr[mid] <= i) lo = mid; else hi = mid;
+    }
+    return lo;
+}
+
+__global__ void k_collate_nodes(const int64_t* __restrict__ ids, const int64_t* __restrict__ node_ptr_all,
+                                const int64_t* __restrict__ out_node_ptr, int G, int64_t N, int64_t* __restrict__ batch,
+                                int64_t* __restrict__ node_src_row) {
+    int64_t n = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (n >= N) return;
+    const int g = seg_of(out_node_ptr, G, n);
+    batch[n] = g;
+    node_src_row[n] = node_ptr_all[ids[g]] + (n - out_node_ptr[g]);
+}
+
+__global__ void k_collate_edges(const int64_t* __restrict__ ids, const int64_t* __restrict__ edge_ptr_all,
+                                const int64_t* __restrict__ out_edge_ptr, const int64_t* __restrict__ out_node_ptr,
+                                const int64_t* __restrict__ edge_local_all, int64_t E_all, int G, int64_t E,
+                                int64_t* __restrict__ edge_index, int64_t* __restrict__ edge_src_slot) {
+    int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= E) return;
+    const int g = seg_of(out_edge_ptr, G, e);
+    const int64_t slot = edge_ptr_all[ids[g]] + (e - out_edge_ptr[g]);
+    const int64_t off = out_node_ptr[g];
+    edge_src_slot[e] = slot;
+    edge_index[e] = edge_local_all[slot] + off;
+    edge_index[E + e] = edge_local_all[E_all + slot] + off;
+}
+
+}  // namespace gsat
+
+extern "C" {
+
+int gsat_collate(const int64_t* graph_ids, int64_t num_graphs, const int64_t* node_ptr_all, const int64_t* edge_ptr_all,
+                 const int64_t* edge_local_all, int64_t num_edges_all, const int64_t* out_node_ptr, const int64_t* out_edge_ptr,
+                 int64_t N, int64_t E, int64_t* batch, int64_t* node_src_row, int64_t* edge_index, int64_t* edge_src_slot, void* stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    GSAT_REQUIRE(num_graphs >= 0 && num_graphs < (1ll << 31) && N >= 0 && E >= 0, GSAT_ERR_ARG, "gsat_collate: bad extents");
+    if (num_graphs == 0) return GSAT_OK;
+    GSAT_REQUIRE(graph_ids && node_ptr_all && edge_ptr_all && out_node_ptr && out_edge_ptr, GSAT_ERR_ARG, "gsat_collate: null pointer");
+    if (N > 0) {
+        GSAT_REQUIRE(batch && node_src_row, GSAT_ERR_ARG, "gsat_collate: null node outputs");
+        gsat::k_collate_nodes<<<GRID1(N)>>>(graph_ids, node_ptr_all, out_node_ptr, (int)num_graphs, N, batch, node_src_row);
+    }
+    if (E > 0) {
+        GSAT_REQUIRE(edge_local_all && edge_index && edge_src_slot, GSAT_ERR_ARG, "gsat_collate: null edge outputs");
+        gsat::k_collate_edges<<<GRID1(E)>>>(graph_ids, edge_ptr_all, out_edge_ptr, out_node_ptr, edge_local_all, num_edges_all, (int)num_graphs, E,
+                                            edge_index, edge_src_slot);
+    }
+    GSAT_LAUNCH_CHECK();
+    return GSAT_OK;
+}
+
+}  // extern "C"
+
+// ------------------------------------------------------------------------------------------------
+// Line ("dual") graph of the fork: one dual node per DIRECTED primal edge; two dual nodes are joined, in both
+// directions, when their primal edges leave the same node (src/datasets/mutag_dual.py:345-377, `group_by_first`).
+// The reference builds it with O(sum deg^2) Python loops per dataset; here one kernel over the by-source CSR.
+// Output order = the reference's: source nodes ascending, then pairs (i < j) in edge order, (e_i,e_j) then (e_j,e_i).
+// ------------------------------------------------------------------------------------------------
+namespace gsat {
+
+__global__ void k_pair_counts(const int32_t* __restrict__ rowptr, int64_t N, int64_t* __restrict__ counts) {
+    int64_t n = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (n >= N) return;
+    const int64_t d = rowptr[n + 1] - rowptr[n];
+    counts[n] = d * (d - 1) / 2;                       // unordered pairs of out-edges of node n
+}
+
+__global__ void k_line_graph(const int32_t* __restrict__ rowptr, const int32_t* __restrict__ eid, const int64_t* __restrict__ pair_ptr,
+                             int64_t N, int64_t num_pairs, int64_t* __restrict__ dual_edge_index) {
+    int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= num_pairs) return;
+    int64_t lo = 0, hi = N;                             // pair_ptr[lo] <= t < pair_ptr[hi]
+    while (hi - lo > 1) {
+        int64_t mid = (lo + hi) >> 1;
+        if (pair_ptr[mid] <= t) lo = mid; else hi = mid;
+    }
+    const int beg = rowptr[lo];
+    const int64_t d = rowptr[lo + 1] - beg;
+    int64_t r = t - pair_ptr[lo];                       // r-th pair (i < j) in row-major order of the upper triangle
+    int64_t i = 0;
+    // rows of the upper triangle have d-1, d-2, ... entries: find i with prefix(i) <= r < prefix(i+1)
+    {
+        // prefix(i) = i*d - i*(i+1)/2 ; solve by a short binary search (d < 2^31)
+        int64_t a = 0, b = d - 1;
+        while (b - a > 1) {
+            int64_t m = (a + b) >> 1;
+            if (m * d - m * (m + 1) / 2 <= r) a = m; else b = m;
+        }
+        i = a;
+    }
+    const int64_t j = i + 1 + (r - (i * d - i * (i + 1) / 2));
+    const int64_t e1 = eid[beg + i], e2 = eid[beg + j];
+    const int64_t E2 = 2 * num_pairs;
+    dual_edge_index[2 * t] = e1;          dual_edge_index[E2 + 2 * t] = e2;
+    dual_edge_index[2 * t + 1] = e2;      dual_edge_index[E2 + 2 * t + 1] = e1;
+}
+
+}  // namespace gsat
+
+extern "C" {
+
+int gsat_line_graph_pair_counts(const int32_t* rowptr_src, int64_t N, int64_t* counts, void* stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    GSAT_REQUIRE(N >= 0, GSAT_ERR_ARG, "gsat_line_graph_pair_counts: bad N");
+    if (N == 0) return GSAT_OK;
+    GSAT_REQUIRE(rowptr_src && counts, GSAT_ERR_ARG, "gsat_line_graph_pair_counts: null pointer");
+    gsat::k_pair_counts<<<GRID1(N)>>>(rowptr_src, N, counts);
+    GSAT_LAUNCH_CHECK();
+    return GSAT_OK;
+}
+
+int gsat_line_graph(const int32_t* rowptr_src, const int32_t* eid_by_src, const int64_t* pair_ptr, int64_t N, int64_t num_pairs,
+                    int64_t* dual_edge_index, void* stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    GSAT_REQUIRE(N >= 0 && num_pairs >= 0, GSAT_ERR_ARG, "gsat_line_graph: bad extents");
+    if (num_pairs == 0) return GSAT_OK;
+    GSAT_REQUIRE(rowptr_src && eid_by_src && pair_ptr && dual_edge_index, GSAT_ERR_ARG, "gsat_line_graph: null pointer");
+    gsat::k_line_graph<<<GRID1(num_pairs)>>>(rowptr_src, eid_by_src, pair_ptr, N, num_pairs, dual_edge_index);
+    GSAT_LAUNCH_CHECK();
+    return GSAT_OK;
+}
+
+}  // extern "C"

@@ -117,7 +117,7 @@ def get_preds(logits, multi_label):
 
 
 def get_model(x_dim, edge_attr_dim, num_class, multi_label, model_config, device):
-    """src/utils/get_model.py:7-16 (SPMotifNet is outside the hot-path scope)."""
+    """src/utils/get_model.py:7-16."""
     from .gin import GIN
     from .pna import PNA
     name = model_config["model_name"]
@@ -126,7 +126,8 @@ def get_model(x_dim, edge_attr_dim, num_class, multi_label, model_config, device
     elif name == "PNA":
         model = PNA(x_dim, edge_attr_dim, num_class, multi_label, model_config)
     elif name == "SPMotifNet":
-        raise NotImplementedError("SPMotifNet / LEConv is not part of the MI355X hot path (SURVEY.md 8f)")
+        from .spmotif_gnn import SPMotifNet
+        model = SPMotifNet(x_dim, edge_attr_dim, num_class, multi_label, model_config)
     else:
         raise ValueError("[ERROR] Unknown model name!")
     return model.to(device)

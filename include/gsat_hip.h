@@ -346,6 +346,33 @@ int gsat_info_loss_bwd(const float* att, const float* r_vec, float r_scalar, con
 /* out[i] = (int32) in[i] */
 int gsat_narrow_i64(const int64_t* in, int64_t n, int32_t* out, void* stream);
 
+/* ================================ device-side batch assembly ================================= */
+
+/*
+ * Collate the graphs `graph_ids` of a packed dataset into one batch, on the device.
+ * Packed dataset: nodes / edges of all graphs concatenated; node_ptr_all / edge_ptr_all int64[G_all+1];
+ * edge_local_all int64[2, num_edges_all] with node ids LOCAL to their graph.
+ * out_node_ptr / out_edge_ptr int64[num_graphs+1] = exclusive scans of the selected graphs' node / edge counts.
+ * Outputs: batch[N] (graph id per node), node_src_row[N] (row of x_all to copy), edge_index[2,E] (offset to batch ids),
+ * edge_src_slot[E] (slot of edge_attr_all / edge_label_all to copy).
+ * replaces: PyG DataLoader collation / Batch.from_data_list (src/utils/get_data_loaders.py:130-145) [3P]: node offset of
+ * edge_index by the cumulative node count, batch[n] = graph id, graph order = order of graph_ids.
+ */
+int gsat_collate(const int64_t* graph_ids, int64_t num_graphs, const int64_t* node_ptr_all, const int64_t* edge_ptr_all,
+                 const int64_t* edge_local_all, int64_t num_edges_all, const int64_t* out_node_ptr,
+                 const int64_t* out_edge_ptr, int64_t N, int64_t E, int64_t* batch, int64_t* node_src_row,
+                 int64_t* edge_index, int64_t* edge_src_slot, void* stream);
+
+/*
+ * Line ("dual") graph: dual node k = primal directed edge k; dual edges join, in both directions, every two primal
+ * edges that leave the same node.  counts[n] = d_n (d_n - 1) / 2; pair_ptr = exclusive scan of counts (int64[N+1]);
+ * dual_edge_index int64[2, 2*num_pairs], ordered: source node ascending, pairs (i<j) in edge-id order, (e_i,e_j),(e_j,e_i).
+ * replaces: the pure-Python pair loops of src/datasets/mutag_dual.py:345-377 (`group_by_first`).
+ */
+int gsat_line_graph_pair_counts(const int32_t* rowptr_src, int64_t num_nodes, int64_t* counts, void* stream);
+int gsat_line_graph(const int32_t* rowptr_src, const int32_t* eid_by_src, const int64_t* pair_ptr, int64_t num_nodes,
+                    int64_t num_pairs, int64_t* dual_edge_index, void* stream);
+
 /* ================================ global pools / segment ops ================================ */
 
 /*

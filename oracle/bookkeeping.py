@@ -118,3 +118,21 @@ def shard_graphs_lpt(edges_per_graph, world_size: int):
         out[r].append(g)
         loads[r] += int(e[g])
     return [sorted(x) for x in out]
+
+
+def line_graph_by_source(edge_index):
+    """Dual edges of the fork, restating src/datasets/mutag_dual.py:345-377: dual node = directed primal edge (by index);
+    primal edges are grouped by their FIRST endpoint in order of first appearance (dict insertion order), and every pair
+    i < j of a group contributes (e_i, e_j) then (e_j, e_i).  (The reference stores endpoint pairs and maps them to
+    indices later; with duplicate-free edge lists that is the index pairing used here.)"""
+    ei = _np(edge_index).astype(np.int64)
+    groups = {}
+    for idx in range(ei.shape[1]):
+        groups.setdefault(int(ei[0, idx]), []).append(idx)
+    out = []
+    for group in groups.values():
+        for i in range(len(group)):
+            for j in range(i + 1, len(group)):
+                out.append((group[i], group[j]))
+                out.append((group[j], group[i]))
+    return np.asarray(out, dtype=np.int64).reshape(-1, 2).T

@@ -341,3 +341,50 @@ class DualGSAT(nn.Module):
         pinfo = ops.info_loss(primal_edge_att, dlog.sigmoid().detach()) * self.pc["info_loss_coef"]                                         # :129-132
         loss = ppred + dpred + pinfo + dinfo + f1
         return primal_edge_att, loss, {"loss": (loss - f1).item(), "pred": dpred.item(), "info": dinfo.item()}, plogits
+
+
+class LEConv(nn.Module):
+    """src/models/conv_layers.py:69-92 ; [3P] PyG LEConv(in, out, bias=True): lin1/lin3 with bias, lin2 without, aggr add."""
+
+    def __init__(self, in_channels, out_channels, bias=True):
+        super().__init__()
+        self.lin1 = nn.Linear(in_channels, out_channels, bias=bias)
+        self.lin2 = nn.Linear(in_channels, out_channels, bias=False)
+        self.lin3 = nn.Linear(in_channels, out_channels, bias=bias)
+
+    def forward(self, x, edge_index, edge_weight=None, edge_atten=None):
+        a, b = self.lin1(x), self.lin2(x)
+        m = a[edge_index[0]] - b[edge_index[1]]                       # a_j - b_i
+        if edge_weight is not None:
+            m = m * edge_weight.view(-1, 1)
+        if edge_atten is not None:
+            m = m * edge_atten
+        return ops.scatter_sum(m, edge_index[1], x.shape[0]) + self.lin3(x)
+
+
+class SPMotifNet(nn.Module):
+    """src/models/spmotif_gnn.py:9-87."""
+
+    def __init__(self, x_dim, edge_attr_dim, num_class, multi_label, model_config):
+        super().__init__()
+        self.n_layers = model_config["n_layers"]
+        H = model_config["hidden_size"]
+        self.node_emb = nn.Linear(x_dim, H)
+        self.convs = nn.ModuleList(LEConv(H, H) for _ in range(self.n_layers))
+        self.relus = nn.ModuleList(nn.ReLU() for _ in range(self.n_layers))
+        self.fc_out = nn.Sequential(nn.Linear(H, 2 * H), nn.ReLU(), nn.Linear(2 * H, num_class))
+        self.conf_mlp = nn.Sequential(nn.Linear(H, 2 * H), nn.ReLU(), nn.Linear(2 * H, 3))
+        self.cq = nn.Linear(3, 3)
+        self.conf_fw = nn.Sequential(self.conf_mlp, self.cq)
+
+    def get_emb(self, x, edge_index, batch, edge_attr, edge_atten=None):
+        x = self.node_emb(x)
+        for conv, relu in zip(self.convs, self.relus):
+            x = relu(conv(x, edge_index, edge_weight=edge_attr, edge_atten=edge_atten))
+        return x
+
+    def get_pred_from_emb(self, emb, batch):
+        return self.fc_out(ops.global_mean_pool(emb, batch, int(batch.max()) + 1))
+
+    def forward(self, x, edge_index, batch, edge_attr, edge_atten=None):
+        return self.get_pred_from_emb(self.get_emb(x, edge_index, batch, edge_attr, edge_atten), batch)

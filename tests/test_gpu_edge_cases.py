@@ -165,3 +165,51 @@ def test_scope_a_at_baseline_size(dev, workload):
         close(got[k], r32[k], ref64=r64[k], what=k)
     for k in ("demb", "dx0", "dW1", "dW3"):
         close(got[k], r32[k], 2e-4, ref64=r64[k], what=k)
+
+
+def test_device_collation_matches_host_collation(dev):
+    """PackedDataset.collate == concatenating the graphs on the host with node-offset edge_index (Batch.from_data_list)."""
+    import dp_gsat_amd as G
+    from types import SimpleNamespace as NS
+    rng = np.random.RandomState(0)
+    graphs = []
+    for i in range(40):
+        n = int(rng.randint(1, 12)); e = int(rng.randint(0, 20))
+        graphs.append(NS(x=torch.randn(n, 5), edge_index=torch.from_numpy(rng.randint(0, n, size=(2, e))).long(),
+                         y=torch.tensor([[float(i % 2)]]), edge_attr=torch.randn(e, 3), edge_label=torch.rand(e)))
+    ds = G.PackedDataset.from_data_list(graphs, dev)
+    for ids in ([3, 4, 5, 6], [39, 0, 17, 17, 2], list(range(40))):
+        b = ds.collate(torch.tensor(ids, device=dev))
+        off, xs, eis, bs, eas = 0, [], [], [], []
+        for k, g in enumerate(ids):
+            gr = graphs[g]
+            xs.append(gr.x); eis.append(gr.edge_index + off); bs += [k] * gr.x.shape[0]; eas.append(gr.edge_attr); off += gr.x.shape[0]
+        assert torch.equal(b.x.cpu(), torch.cat(xs)) and torch.equal(b.edge_index.cpu(), torch.cat(eis, dim=1))
+        assert torch.equal(b.batch.cpu(), torch.tensor(bs)) and torch.equal(b.edge_attr.cpu(), torch.cat(eas))
+        assert torch.equal(b.y.cpu(), torch.cat([graphs[g].y for g in ids])) and b.num_graphs == len(ids)
+
+
+def test_line_graph_bit_exact(dev):
+    """Device line-graph construction == the reference's pair loops, on the MUTAG fixture and the line-graph size recorded in the reference (comment at mutag_dual.py:385
+    counts 451 808 dual edges for the whole dataset; here the first 128 kept graphs)."""
+    import os
+    import dp_gsat_amd as G
+    z = np.load(os.path.join(os.path.dirname(__file__), "golden", "mutag128.npz"))
+    ei = torch.from_numpy(z["edge_index"].astype(np.int64))
+    batch = torch.from_numpy(z["batch"].astype(np.int64))
+    N = batch.shape[0]
+    order = torch.sort(ei[0], stable=True)[1]                      # source-sorted copy: group order == ascending source id
+    ei = ei[:, order].contiguous()
+    want = obk.line_graph_by_source(ei)
+    dei, dbatch = G.line_graph(ei.to(dev), N, batch.to(dev))
+    assert np.array_equal(dei.cpu().numpy(), want)                 # bit-exact, including the order of the dual edges
+    assert torch.equal(dbatch.cpu(), batch[ei[0]])
+    deg = torch.bincount(ei[0], minlength=N)
+    assert dei.shape[1] == int((deg * (deg - 1)).sum())
+    # unsorted edge list: same SET of dual edges (group order then follows ascending source id instead of first appearance)
+    perm = torch.randperm(ei.shape[1], generator=torch.Generator().manual_seed(0))
+    ei2 = ei[:, perm].contiguous()
+    w2 = obk.line_graph_by_source(ei2)
+    d2 = G.line_graph(ei2.to(dev), N)[0].cpu().numpy()
+    key = lambda a: np.sort(a[0] * ei.shape[1] + a[1])
+    assert np.array_equal(key(d2), key(w2))

@@ -15,7 +15,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 def _mk_pair(G, backbone, cfg, x_dim, e_dim, H, learn_edge_att, dev, num_class=2):
-    oclf = (om.GIN if backbone == "GIN" else om.PNA)(x_dim, e_dim, num_class, False, cfg)
+    oclf = {"GIN": om.GIN, "PNA": om.PNA, "SPMotifNet": om.SPMotifNet}[backbone](x_dim, e_dim, num_class, False, cfg)
     oext = om.ExtractorMLP(H, learn_edge_att)
     clf = G.get_model(x_dim, e_dim, num_class, False, cfg, dev)
     clf.load_state_dict(oclf.state_dict())
@@ -225,3 +225,16 @@ def test_batchnorm_kernels(dev, relu, training):
     close(mine.weight.grad, ref.weight.grad); close(mine.bias.grad, ref.bias.grad)
     close(mine.running_mean, ref.running_mean, 1e-5); close(mine.running_var, ref.running_var, 1e-5)
     assert int(mine.num_batches_tracked) == int(ref.num_batches_tracked)
+
+
+def test_gsat_spmotifnet_leconv(dev):
+    """src/configs/SPMotifNet-spmotif.yml: LEConv backbone, hidden 32, edge attention on directed spmotif graphs,
+    edge_attr = ones passed as edge_weight."""
+    import dp_gsat_amd as G
+    from dp_gsat_amd import synth
+    data = synth.spmotif_batch(num_graphs=12, seed=3)
+    H = 32
+    cfg = dict(model_name="SPMotifNet", n_layers=2, hidden_size=H)
+    pair = _mk_pair(G, "SPMotifNet", cfg, 4, 1, H, True, dev, num_class=3)
+    assert list(pair[2].state_dict()) == list(pair[0].state_dict())
+    _step(G, data, *pair, True, H, dev, True, num_class=3)

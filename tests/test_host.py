@@ -70,6 +70,8 @@ def test_state_dict_keys_match_reference_layout():
         assert list(sd_m.keys()) == list(sd_r.keys())
         assert all(sd_m[k].shape == sd_r[k].shape for k in sd_m)
         mine.load_state_dict(sd_r)
+    sp_cfg = dict(model_name="SPMotifNet", n_layers=2, hidden_size=32)
+    assert list(G.get_model(4, 1, 3, False, sp_cfg, "cpu").state_dict()) == list(om.SPMotifNet(4, 1, 3, False, sp_cfg).state_dict())
     # keys the reference's checkpoints carry
     keys = set(G.get_model(7, 0, 2, False, dict(model_name="GIN", n_layers=2, hidden_size=16, dropout_p=0.3), "cpu").state_dict())
     assert {"node_encoder.weight", "convs.0.eps", "convs.0.nn.0.weight", "convs.0.nn.1.running_mean",
