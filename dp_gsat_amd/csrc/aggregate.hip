@@ -421,7 +421,7 @@ static inline void span_grid(int64_t num_rows, int lpr, int* nblocks, int* rows_
     const int gpb = AGG_BLOCK / lpr;
     int64_t groups_needed = num_rows;                       // one row per group if the grid allows it
     int64_t nb = ceil_div(groups_needed, gpb);
-    const int64_t cap = 256 * 16;                            // 16 blocks per CU worth of work items
+    const int64_t cap = 256 * 64;                            // one row per lane group up to 16k blocks (shorter per-wave chains)
     if (nb > cap) nb = cap;
     if (nb < 1) nb = 1;
     *nblocks = (int)nb;

@@ -345,7 +345,7 @@ static inline int pna_lpr(int64_t H) {
 static inline void pna_grid(int64_t N, int lpr, int* nb, int* rpg) {
     const int gpb = PNA_BLOCK / lpr;
     int64_t b = ceil_div(N, gpb);
-    if (b > 256 * 16) b = 256 * 16;
+    if (b > 256 * 64) b = 256 * 64;          // one row per lane group up to 16k blocks: shorter per-wave dependency chains
     if (b < 1) b = 1;
     *nb = (int)b;
     *rpg = (int)std::max<int64_t>(1, ceil_div(N, b * gpb));
