@@ -13,7 +13,7 @@
 
 namespace gsat {
 
-constexpr int PNA_BLOCK = 256;
+constexpr int PNA_BLOCK = 128;
 constexpr int AGG_SUM = 0, AGG_MEAN = 1, AGG_MIN = 2, AGG_MAX = 3, AGG_VAR = 4, AGG_STD = 5;
 constexpr int SC_ID = 0, SC_AMP = 1, SC_ATT = 2, SC_LIN = 3, SC_INVLIN = 4;
 
