@@ -153,18 +153,25 @@ __global__ __launch_bounds__(PNA_BLOCK) void k_pna_fwd(
 }
 
 template <int LPR, bool HAS_EE>
-__global__ __launch_bounds__(PNA_BLOCK) void k_pna_bwd_dst(
+__global__ __launch_bounds__(PNA_BLOCK, HAS_EE ? 2 : 4) void k_pna_bwd_dst(
     const float* __restrict__ x, const float* __restrict__ att, const float* __restrict__ edge_emb,
     const float* __restrict__ dout, const int32_t* __restrict__ rowptr, const int32_t* __restrict__ col,
     const int32_t* __restrict__ eid, int num_rows, int H, PnaCfg cfg, float* __restrict__ dx_self,
     float* __restrict__ dmsg, float* __restrict__ datt, float* __restrict__ dedge, int rows_per_group) {
     constexpr int GPB = PNA_BLOCK / LPR;
+    // The upstream gradient row (S*A*parts segments of H floats, 64 % of the kernel's bytes) is fetched by LDS-DMA at
+    // the top of the row, so its HBM latency overlaps the index -> att -> x_j dependency chain without holding VGPRs.
+    constexpr int MAXSEG = 8;
+    __shared__ float4 stage[MAXSEG][PNA_BLOCK];
     const int lane = threadIdx.x % LPR;
     const int c = lane * 4;
     const bool on = c < H;
     const int parts = HAS_EE ? 3 : 2;
     const int F = parts * H;
     const size_t out_stride = (size_t)cfg.S * cfg.A * F;
+    const int nseg = cfg.S * cfg.A * parts;
+    const bool staged = nseg <= MAXSEG;
+    const int wave_base = (threadIdx.x >> 6) << 6;
     const int grp = pna_xcd_remap(blockIdx.x, gridDim.x) * GPB + threadIdx.x / LPR;
     int row = grp * rows_per_group;
     const int row_end = min(num_rows, row + rows_per_group);
@@ -174,6 +181,12 @@ __global__ __launch_bounds__(PNA_BLOCK) void k_pna_bwd_dst(
         if (end == beg) {          // no in-edges: every aggregate is a constant of x
             if (on) st4(dx_self + (size_t)row * H + c, f4zero());
             continue;
+        }
+        if (staged && on) {
+            const float* g0 = dout + (size_t)row * out_stride + c;
+            for (int sg = 0; sg < nseg; ++sg)
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(g0 + (size_t)sg * H),
+                                                 (__attribute__((address_space(3))) void*)&stage[sg][wave_base], 16, 0, 0);
         }
         // ---- pass 1: row statistics and first-occurrence args ---------------------------------
         float sa = 0.f, sa2 = 0.f, amin = INFINITY, amax = -INFINITY;
@@ -238,6 +251,7 @@ __global__ __launch_bounds__(PNA_BLOCK) void k_pna_bwd_dst(
         if (on) {
             const float n = fmaxf(cnt, 1.f), inv_n = 1.f / n;
             const float* drow = dout + (size_t)row * out_stride + c;
+            if (staged) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // the LDS-DMA of this row has landed
 #define GSAT_FOLD(ACC, PART, P, Q, GMN, GMX)                                                                           \
             {                                                                                                          \
                 const float4 mean = f4scale(inv_n, ACC.s);                                                             \
@@ -249,7 +263,8 @@ __global__ __launch_bounds__(PNA_BLOCK) void k_pna_bwd_dst(
                 for (int s = 0; s < cfg.S; ++s) {                                                                      \
                     const float f = scaler_factor(cfg.scal[s], cnt, cfg.avg_lin, cfg.avg_log);                         \
                     for (int a = 0; a < cfg.A; ++a) {                                                                  \
-                        const float4 v = f4scale(f, ld4(drow + (size_t)(s * cfg.A + a) * F + (PART) * H));             \
+                        const int sg_ = (s * cfg.A + a) * parts + (PART);                                              \
+                        const float4 v = f4scale(f, staged ? stage[sg_][threadIdx.x] : ld4(drow + (size_t)sg_ * H));   \
                         switch (cfg.aggr[a]) {                                                                         \
                             case AGG_SUM: p0.x += v.x; p0.y += v.y; p0.z += v.z; p0.w += v.w; break;                   \
                             case AGG_MEAN: p0 = f4fma(inv_n, v, p0); break;                                            \
