@@ -208,7 +208,7 @@ def aggregation_roofline(wl, data, dev, reps=30, rounds=5):
         ee = torch.randn(E, H, device=dev) if data.edge_attr is not None else None
         def launch():
             call("gsat_aggr_sum_fwd", ptr(x), None, ptr(att), ptr(ee), ptr(ix.rowptr_dst), ptr(ix.src_by_dst), ptr(ix.eid_by_dst),
-                 N, E, H, 1.0, ptr(y), ptr(ix.chunk_ptr_dst), ptr(ix.partial(H)), stream())
+                 N, E, H, 1.0, ptr(y), ptr(ix.long_rows[0]), ptr(ix.partial(H)) if ix.long_rows[0] is not None else None, stream())
         alg_bytes = 8 * N * H + 8 * E + 4 * N + (4 * E * H if ee is not None else 0)   # SURVEY 8d (+ edge_emb read for GINE)
         kname = "k_aggr_sum_fwd"
     for _ in range(5):

@@ -59,6 +59,7 @@ class BatchIndex:
         call("gsat_row_chunks", ptr(self.rowptr_dst), N, ptr(self.chunk_ptr_dst), ptr(cws), cws_bytes, stream())
         call("gsat_row_chunks", ptr(self.rowptr_src), N, ptr(self.chunk_ptr_src), ptr(cws), cws_bytes, stream())
         self._partials = {}
+        self._long = None
         # int32 copies of the two edge_index rows (original edge order) for the per-edge kernels
         self.src32 = _i32(E, dev)
         self.dst32 = _i32(E, dev)
@@ -69,6 +70,19 @@ class BatchIndex:
         self._undirected = None
         self._slot_dst_of_srcslot = None
         self._graphs = {}
+
+    @property
+    def long_rows(self):
+        """(by-destination, by-source) chunk lists, or (None, None) when no row has more than GSAT_LONG_ROW_EDGES
+        entries -- then the aggregation calls skip the hub-chunk launch.  Costs one small read-back per index
+        (per collated batch), merged with the undirected-flag read when that one is needed too."""
+        if self._long is None:
+            if self.E <= 256:
+                self._long = (False, False)
+            else:
+                t = torch.stack([self.chunk_ptr_dst[-1], self.chunk_ptr_src[-1]]).tolist()
+                self._long = (t[0] > 0, t[1] > 0)
+        return (self.chunk_ptr_dst if self._long[0] else None, self.chunk_ptr_src if self._long[1] else None)
 
     def partial(self, H: int) -> torch.Tensor:
         """Scratch for the long-row partial sums of width H (upper bound, no host sync); reused across calls

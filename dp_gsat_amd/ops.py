@@ -49,7 +49,7 @@ class MaskedSumAggregate(torch.autograd.Function):
         out = torch.empty_like(x)
         call("gsat_aggr_sum_fwd", ptr(x), None, ptr(attf), ptr(edge_emb), ptr(index.rowptr_dst),
              ptr(index.src_by_dst), ptr(index.eid_by_dst), N, index.E, H, float(self_coef), ptr(out),
-             ptr(index.chunk_ptr_dst), ptr(index.partial(H)), stream())
+             ptr(index.long_rows[0]), ptr(index.partial(H)) if index.long_rows[0] is not None else None, stream())
         ctx.save_for_backward(x, attf, edge_emb)
         ctx.index, ctx.self_coef = index, float(self_coef)
         ctx.att_shape = None if att is None else att.shape
@@ -68,7 +68,7 @@ class MaskedSumAggregate(torch.autograd.Function):
         dee = torch.empty_like(edge_emb) if need_ee else None
         call("gsat_aggr_sum_bwd", ptr(x), ptr(attf), ptr(edge_emb), ptr(dout), ptr(index.rowptr_src),
              ptr(index.dst_by_src), ptr(index.eid_by_src), N, index.E, H, ctx.self_coef, ptr(dx), ptr(datt), ptr(dee),
-             ptr(index.chunk_ptr_src), ptr(index.partial(H)), stream())
+             ptr(index.long_rows[1]), ptr(index.partial(H)) if index.long_rows[1] is not None else None, stream())
         return dx, (datt.view(ctx.att_shape) if need_att else None), dee, None, None
 
 
@@ -162,7 +162,7 @@ class PnaAggregate(torch.autograd.Function):
         dx = torch.empty_like(x)
         call("gsat_aggr_sum_fwd", ptr(dmsg), ptr(dx_self), None, None, ptr(index.rowptr_src),
              ptr(index.slot_dst_of_srcslot), None, N, index.E, H, 1.0, ptr(dx),
-             ptr(index.chunk_ptr_src), ptr(index.partial(H)), stream())
+             ptr(index.long_rows[1]), ptr(index.partial(H)) if index.long_rows[1] is not None else None, stream())
         return dx, (datt.view(ctx.att_shape) if need_att else None), dee, None, None, None, None, None
 
 
@@ -266,7 +266,7 @@ class ExtractorAttention(torch.autograd.Function):
         if edge_mode:
             g.rowptr_src, g.eid_by_src = ptr(index.rowptr_src), ptr(index.eid_by_src)
             g.rowptr_dst, g.eid_by_dst = ptr(index.rowptr_dst), ptr(index.eid_by_dst)
-            g.chunk_ptr_src, g.chunk_ptr_dst = ptr(index.chunk_ptr_src), ptr(index.chunk_ptr_dst)
+            g.chunk_ptr_dst, g.chunk_ptr_src = (ptr(t) for t in index.long_rows)
         demb = torch.empty_like(emb)
         grads = [torch.empty_like(t) for t in params]
         g.demb = ptr(demb)
