@@ -107,13 +107,6 @@ __device__ __forceinline__ uint4 philox4x32(uint64_t seed, uint32_t c0, uint32_t
     }
     return make_uint4(c0, c1, c2, c3);
 }
-// keep-probability test for column `col` of row `row` in RNG stream `sid`
-__device__ __forceinline__ float philox_keep(uint64_t seed, uint32_t sid, uint32_t row, uint32_t col, float p_drop) {
-    uint4 r = philox4x32(seed, row, col >> 2, sid, 0x5A17u);
-    uint32_t w = (col & 3) == 0 ? r.x : (col & 3) == 1 ? r.y : (col & 3) == 2 ? r.z : r.w;
-    float u = (float)(w >> 8) * (1.0f / 16777216.0f);   // [0,1)
-    return u >= p_drop ? 1.0f : 0.0f;
-}
 #endif
 
 }  // namespace gsat

@@ -14,8 +14,8 @@
 namespace gsat {
 
 constexpr int PNA_BLOCK = 128;
-constexpr int AGG_SUM = 0, AGG_MEAN = 1, AGG_MIN = 2, AGG_MAX = 3, AGG_VAR = 4, AGG_STD = 5;
-constexpr int SC_ID = 0, SC_AMP = 1, SC_ATT = 2, SC_LIN = 3, SC_INVLIN = 4;
+constexpr int AGG_SUM = GSAT_AGG_SUM, AGG_MEAN = GSAT_AGG_MEAN, AGG_MIN = GSAT_AGG_MIN, AGG_MAX = GSAT_AGG_MAX, AGG_VAR = GSAT_AGG_VAR;
+constexpr int SC_AMP = GSAT_SCALE_AMPLIFICATION, SC_ATT = GSAT_SCALE_ATTENUATION, SC_LIN = GSAT_SCALE_LINEAR, SC_INVLIN = GSAT_SCALE_INVERSE_LINEAR;
 
 struct PnaCfg {
     int A, S;
