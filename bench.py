@@ -128,7 +128,7 @@ class HotPath:
 class FullStep:
     """Whole GSAT training step (example/trainer.py:28-36): forward_pass, zero_grad, backward, Adam."""
 
-    def __init__(self, wl, data, x_dim, e_dim, dev):
+    def __init__(self, wl, data, x_dim, e_dim, dev, capturable=False):
         import dp_gsat_amd as G
         from dp_gsat_amd import synth
         self.G, self.data = G, data
@@ -139,7 +139,7 @@ class FullStep:
         self.clf = G.get_model(x_dim, e_dim, num_class, False, cfg, dev)
         self.ext = G.ExtractorMLP(H, wl["edge_att"]).to(dev)
         params = list(self.clf.parameters()) + list(self.ext.parameters())
-        self.opt = torch.optim.Adam(params, lr=1e-3, weight_decay=3e-6)
+        self.opt = torch.optim.Adam(params, lr=1e-3, weight_decay=3e-6, capturable=capturable)
         self.gsat = G.GSAT(self.clf, self.ext, G.Criterion(num_class, False), self.opt, learn_edge_att=wl["edge_att"]).train()
         self.gsat.sync_loss_dict = False
         self.flat = None
@@ -315,6 +315,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-full-step", action="store_true")
     ap.add_argument("--cpu-sample-graphs", type=int, default=0)
+    ap.add_argument("--graph", action="store_true", help="capture the scope-A step into a hipGraph (torch.cuda.graph) and time replays")
     ap.add_argument("--roofline-only", action="store_true", help="only run the aggregation-kernel roofline leg (for rocprofv3 --pmc passes)")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only to rehearse N>1 on one GPU)")
     args = ap.parse_args()
@@ -356,7 +357,23 @@ def main():
     hot.reuse_index = args.reuse_index
     if distributed:
         hot.attach_dp()
-    dt = timed(hot.step, args.steps, args.warmup, dev, distributed)
+    def captured(fn):
+        """Capture one call of `fn` into a hipGraph (after eager warm-up on a side stream) and return the replay callable."""
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            for _ in range(3):
+                fn()
+        torch.cuda.current_stream().wait_stream(side)
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph):
+            fn()
+        return graph.replay
+
+    import dp_gsat_amd as G
+    G.set_sync_free(bool(args.graph))            # graph mode: no host read-backs inside the step, so it is capturable
+    step_fn = captured(hot.step) if args.graph else hot.step
+    dt = timed(step_fn, args.steps, args.warmup, dev, distributed)
     e_local = torch.tensor([float(data.num_edges), float(data.num_nodes)], dtype=torch.float64, device=dev)
     if distributed:
         dist.all_reduce(e_local)
@@ -366,14 +383,16 @@ def main():
 
     full = None
     if not args.no_full_step:
-        fs = FullStep(wl, data, x_dim, e_dim, dev)
+        fs = FullStep(wl, data, x_dim, e_dim, dev, capturable=args.graph)
         if distributed:
             fs.attach_dp()
-        fdt = timed(fs.step, max(args.steps // 2, 3), max(args.warmup // 2, 2), dev, distributed)
+        fstep = captured(fs.step) if args.graph else fs.step
+        fdt = timed(fstep, max(args.steps // 2, 3), max(args.warmup // 2, 2), dev, distributed)
         fsteps = max(args.steps // 2, 3)
         full = dict(value=round(e_total / (fdt / fsteps) / 1e6, 3), unit="million edges/s", ms_per_step=round(fdt / fsteps * 1e3, 3),
                     what="whole GSAT training step: 2 backbone passes + extractor + losses + backward + Adam (+ all-reduce)")
 
+    G.set_sync_free(False)
     roof, cpu = None, None
     if rank == 0:
         hot.reuse_index = True
@@ -391,7 +410,7 @@ def main():
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": wl["desc"], "graphs_per_gpu": wl["graphs"], "nodes_total": int(n_total), "edges_total": int(e_total),
                        "hidden": wl["H"], "layers": wl["L"], "attention": "edge" if wl["edge_att"] else "node",
-                       "parallelism": f"dp{world}", "index_rebuilt_every_step": not args.reuse_index},
+                       "parallelism": f"dp{world}", "index_rebuilt_every_step": not args.reuse_index, "hipgraph": bool(args.graph)},
             "roofline": roof, "cpu_baseline": cpu, "full_step": full,
         }
         if cpu:

@@ -51,7 +51,7 @@ SIGNATURES = {
     "gsat_sample_bwd": (INT, [P, P, F32, I64, P, P]),
     "gsat_lift_fwd": (INT, [P, P, P, I64, P, P]),
     "gsat_lift_bwd": (INT, [P, P, P, P, P, P, P, P, I64, P, P]),
-    "gsat_symmetrise": (INT, [P, P, I64, P, P]),
+    "gsat_symmetrise": (INT, [P, P, P, I64, P, P]),
     "gsat_info_loss_fwd": (INT, [P, P, F32, I64, P, P, P]),
     "gsat_info_loss_bwd": (INT, [P, P, F32, P, I64, P, P]),
     "gsat_collate": (INT, [P, I64, P, P, P, I64, P, P, I64, I64, P, P, P, P, P]),
@@ -72,7 +72,7 @@ class AttnArgs(ctypes.Structure):
                 ("W1", P), ("b1", P), ("W2", P), ("b2", P), ("W3", P), ("b3", P),
                 ("emb", P), ("mask1", P), ("mask2", P), ("u", P),
                 ("P", P), ("Q", P), ("a1", P), ("h2", P), ("stats", P), ("logits", P), ("att", P),
-                ("fwd_workspace", P), ("fwd_workspace_bytes", SZ)]
+                ("fwd_workspace", P), ("fwd_workspace_bytes", SZ), ("seed_dev", P)]
 
 
 class AttnGrads(ctypes.Structure):

@@ -46,10 +46,18 @@ struct PreAct {
     }
 };
 
-__device__ __forceinline__ float4 keep4(const float* mask, uint64_t seed, int layer, int row, int c, int C, float p, bool training) {
+// Philox seed by value, or read from device memory (`dev` != NULL): a captured hipGraph then draws a new dropout mask on
+// every replay because the host (or a graph-safe RNG op) rewrites that word between replays.
+struct SeedRef {
+    uint64_t value;
+    const uint64_t* dev;
+    __device__ __forceinline__ uint64_t get() const { return dev ? *dev : value; }
+};
+
+__device__ __forceinline__ float4 keep4(const float* mask, SeedRef sref, int layer, int row, int c, int C, float p, bool training) {
     if (!training || p <= 0.f) return make_float4(1.f, 1.f, 1.f, 1.f);
     if (mask) return ld4(mask + (size_t)row * C + c);
-    uint4 r = philox4x32(seed, (uint32_t)row, (uint32_t)(c >> 2), (uint32_t)layer, 0x5A17u);
+    uint4 r = philox4x32(sref.get(), (uint32_t)row, (uint32_t)(c >> 2), (uint32_t)layer, 0x5A17u);
     const float k = 1.0f / 16777216.0f;
     return make_float4((float)(r.x >> 8) * k >= p ? 1.f : 0.f, (float)(r.y >> 8) * k >= p ? 1.f : 0.f,
                        (float)(r.z >> 8) * k >= p ? 1.f : 0.f, (float)(r.w >> 8) * k >= p ? 1.f : 0.f);
@@ -172,7 +180,7 @@ __global__ __launch_bounds__(SB) void k_seg_stats(PreAct<EDGE> pre, const int32_
 // a[m,c] = relu((h - mean) * rstd) * keep / (1-p)     (elementwise over [M, C]); RELU=false: plain norm
 template <bool EDGE, bool RELU>
 __global__ void k_norm_apply(PreAct<EDGE> pre, const int32_t* __restrict__ row_seg, const float* __restrict__ mean,
-                             const float* __restrict__ rstd, const float* __restrict__ mask, uint64_t seed, int layer,
+                             const float* __restrict__ rstd, const float* __restrict__ mask, SeedRef seed, int layer,
                              float p, int training, int64_t M, float* __restrict__ out) {
     const int C = pre.C, C4 = C >> 2;
     const float sc = (training && p > 0.f) ? 1.f / (1.f - p) : 1.f;
@@ -194,7 +202,7 @@ __global__ void k_norm_apply(PreAct<EDGE> pre, const int32_t* __restrict__ row_s
 template <int LPR>
 __global__ __launch_bounds__(256) void k_head_fwd(const float* __restrict__ h2, const float* __restrict__ b2,
                                                   const int32_t* __restrict__ row_seg, const float* __restrict__ mean,
-                                                  const float* __restrict__ rstd, const float* __restrict__ mask, uint64_t seed,
+                                                  const float* __restrict__ rstd, const float* __restrict__ mask, SeedRef seed,
                                                   float p, int training, const float* __restrict__ w3, const float* __restrict__ b3,
                                                   const float* __restrict__ u, int64_t M, int C, float* __restrict__ logits,
                                                   float* __restrict__ att) {
@@ -242,7 +250,7 @@ __global__ void k_dz(const float* __restrict__ dlogits, const float* __restrict_
 __global__ __launch_bounds__(SB) void k_head_bwd_stats(const float* __restrict__ h2, const float* __restrict__ b2,
                                                        const int32_t* __restrict__ seg_ptr, const int32_t* __restrict__ order,
                                                        const float* __restrict__ mean, const float* __restrict__ rstd,
-                                                       const float* __restrict__ mask, uint64_t seed, float p, int training,
+                                                       const float* __restrict__ mask, SeedRef seed, float p, int training,
                                                        const float* __restrict__ w3, const float* __restrict__ dz, int C,
                                                        float* __restrict__ S1, float* __restrict__ S2, float* __restrict__ dw3p) {
     __shared__ float4 sm[SB_SLOTS][SB_LANES];
@@ -285,7 +293,7 @@ __global__ __launch_bounds__(SB) void k_head_bwd_stats(const float* __restrict__
 
 // dh2[m,c] = rstd2 * (dy2 - S1 - yhat2 * S2)
 __global__ void k_dh2(const float* __restrict__ h2, const float* __restrict__ b2, const int32_t* __restrict__ row_seg,
-                      const float* __restrict__ mean, const float* __restrict__ rstd, const float* __restrict__ mask, uint64_t seed,
+                      const float* __restrict__ mean, const float* __restrict__ rstd, const float* __restrict__ mask, SeedRef seed,
                       float p, int training, const float* __restrict__ w3, const float* __restrict__ dz,
                       const float* __restrict__ S1, const float* __restrict__ S2, int64_t M, int C, float* __restrict__ dh2) {
     const int C4 = C >> 2;
@@ -437,7 +445,7 @@ __global__ void k_philox_mask(uint64_t seed, int layer, int64_t M, int C, float 
     const int C4 = C >> 2;
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < M * C4; i += (int64_t)gridDim.x * blockDim.x) {
         const int m = (int)(i / C4), c = (int)(i % C4) * 4;
-        st4(keep + (size_t)m * C + c, keep4(nullptr, seed, layer, m, c, C, p, true));
+        st4(keep + (size_t)m * C + c, keep4(nullptr, SeedRef{seed, nullptr}, layer, m, c, C, p, true));
     }
 }
 
@@ -545,11 +553,11 @@ int gsat_attn_fwd(const gsat_attn_args* a, void* stream_) {
     if (a->edge_mode) {
         PreAct<true> pre{a->P, a->Q, a->b1, a->src, a->dst, C1};
         if ((rc = launch_seg_stats<true>(stream, pre, a->seg_ptr, a->seg_order, G, Z, mean1, rstd1, part))) return rc;
-        k_norm_apply<true, true><<<ew_blocks(M * (C1 / 4)), 256, 0, stream>>>(pre, a->row_seg, mean1, rstd1, a->mask1, a->seed, 1, a->p_drop, a->training, M, a->a1);
+        k_norm_apply<true, true><<<ew_blocks(M * (C1 / 4)), 256, 0, stream>>>(pre, a->row_seg, mean1, rstd1, a->mask1, SeedRef{a->seed, a->seed_dev}, 1, a->p_drop, a->training, M, a->a1);
     } else {
         PreAct<false> pre{a->P, nullptr, a->b1, nullptr, nullptr, C1};
         if ((rc = launch_seg_stats<false>(stream, pre, a->seg_ptr, a->seg_order, G, Z, mean1, rstd1, part))) return rc;
-        k_norm_apply<false, true><<<ew_blocks(M * (C1 / 4)), 256, 0, stream>>>(pre, a->row_seg, mean1, rstd1, a->mask1, a->seed, 1, a->p_drop, a->training, M, a->a1);
+        k_norm_apply<false, true><<<ew_blocks(M * (C1 / 4)), 256, 0, stream>>>(pre, a->row_seg, mean1, rstd1, a->mask1, SeedRef{a->seed, a->seed_dev}, 1, a->p_drop, a->training, M, a->a1);
     }
     GSAT_LAUNCH_CHECK();
     // ---- layer 2 ----------------------------------------------------------------------------
@@ -562,7 +570,7 @@ int gsat_attn_fwd(const gsat_attn_args* a, void* stream_) {
     const int q = C2 / 4;
     const int lpr = q <= 4 ? 4 : q <= 8 ? 8 : q <= 16 ? 16 : q <= 32 ? 32 : 64;
     const int nb = (int)std::min<int64_t>(ceil_div(M, 256 / lpr), 256 * 32);
-#define HEAD(L) k_head_fwd<L><<<nb, 256, 0, stream>>>(a->h2, a->b2, a->row_seg, mean2, rstd2, a->mask2, a->seed, a->p_drop, a->training, a->W3, a->b3, a->u, M, C2, a->logits, a->att)
+#define HEAD(L) k_head_fwd<L><<<nb, 256, 0, stream>>>(a->h2, a->b2, a->row_seg, mean2, rstd2, a->mask2, SeedRef{a->seed, a->seed_dev}, a->p_drop, a->training, a->W3, a->b3, a->u, M, C2, a->logits, a->att)
     switch (lpr) { case 4: HEAD(4); break; case 8: HEAD(8); break; case 16: HEAD(16); break; case 32: HEAD(32); break; default: HEAD(64); break; }
 #undef HEAD
     GSAT_LAUNCH_CHECK();
@@ -650,7 +658,7 @@ int gsat_attn_bwd(const gsat_attn_args* a, const gsat_attn_grads* gr, void* stre
     if ((rc = colsum(stream, dz, M, 1, gr->db3, scratch))) return rc;
     // ---- through the head and the second InstanceNorm ------------------------------------------
     const dim3 g2((unsigned)G, (unsigned)ceil_div(C2, 64), (unsigned)Z), g1((unsigned)G, (unsigned)ceil_div(C1, 64), (unsigned)Z);
-    k_head_bwd_stats<<<g2, SB, 0, stream>>>(a->h2, a->b2, a->seg_ptr, a->seg_order, mean2, rstd2, a->mask2, a->seed, a->p_drop,
+    k_head_bwd_stats<<<g2, SB, 0, stream>>>(a->h2, a->b2, a->seg_ptr, a->seg_order, mean2, rstd2, a->mask2, SeedRef{a->seed, a->seed_dev}, a->p_drop,
                                             a->training, a->W3, dz, C2, Z > 1 ? zp1 : S1, Z > 1 ? zp2 : S2, Z > 1 ? zp3 : dw3p);
     if (Z > 1) {
         const unsigned cb = (unsigned)ceil_div(G * C2, 256);
@@ -660,7 +668,7 @@ int gsat_attn_bwd(const gsat_attn_args* a, const gsat_attn_grads* gr, void* stre
     }
     GSAT_LAUNCH_CHECK();
     if ((rc = colsum(stream, dw3p, G, C2, gr->dW3, scratch))) return rc;
-    k_dh2<<<ew_blocks(M * (C2 / 4)), 256, 0, stream>>>(a->h2, a->b2, a->row_seg, mean2, rstd2, a->mask2, a->seed, a->p_drop, a->training,
+    k_dh2<<<ew_blocks(M * (C2 / 4)), 256, 0, stream>>>(a->h2, a->b2, a->row_seg, mean2, rstd2, a->mask2, SeedRef{a->seed, a->seed_dev}, a->p_drop, a->training,
                                                        a->W3, dz, S1, S2, M, C2, dh2);
     GSAT_LAUNCH_CHECK();
     // b1 and b2 sit in front of an InstanceNorm, which removes any per-channel constant of its segment: their
@@ -712,7 +720,7 @@ int gsat_instance_norm_fwd(const float* x, const int32_t* seg_ptr, const int32_t
     float* rstd = stats + (size_t)G * C;
     PreAct<false> pre{x, nullptr, nullptr, nullptr, nullptr, (int)C};
     k_seg_stats<false><<<dim3((unsigned)G, (unsigned)ceil_div(C, 64), 1), SB, 0, stream>>>(pre, seg_ptr, seg_order, mean, rstd);
-    k_norm_apply<false, false><<<ew_blocks(M * (C / 4)), 256, 0, stream>>>(pre, row_seg, mean, rstd, nullptr, 0, 0, 0.f, 0, M, y);
+    k_norm_apply<false, false><<<ew_blocks(M * (C / 4)), 256, 0, stream>>>(pre, row_seg, mean, rstd, nullptr, SeedRef{0, nullptr}, 0, 0.f, 0, M, y);
     GSAT_LAUNCH_CHECK();
     return GSAT_OK;
 }

@@ -45,9 +45,12 @@ __global__ void k_lift_bwd(const float* __restrict__ a, const float* __restrict_
 }
 
 // out[k] = (a[k] + a[rev[k]]) / 2 ; rev is an involution so the same kernel is its own backward
-__global__ void k_symmetrise(const float* __restrict__ a, const int32_t* __restrict__ rev, int64_t E, float* __restrict__ out) {
+__global__ void k_symmetrise(const float* __restrict__ a, const int32_t* __restrict__ rev, const int32_t* __restrict__ flag, int64_t E,
+                             float* __restrict__ out) {
     int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (e < E) out[e] = (a[e] + a[rev[e]]) / 2.f;
+    if (e >= E) return;
+    const bool sym = flag == nullptr || flag[0] != 0;       // device-side `if is_undirected(...)`: no host round trip
+    out[e] = sym ? (a[e] + a[rev[e]]) / 2.f : a[e];
 }
 
 __device__ __forceinline__ float info_term(float a, float r) {
@@ -149,12 +152,12 @@ int gsat_lift_bwd(const float* node_att, const float* dedge_att, const int32_t* 
     return GSAT_OK;
 }
 
-int gsat_symmetrise(const float* att, const int32_t* rev, int64_t E, float* out, void* stream_) {
+int gsat_symmetrise(const float* att, const int32_t* rev, const int32_t* undirected_flag, int64_t E, float* out, void* stream_) {
     hipStream_t stream = (hipStream_t)stream_;
     GSAT_REQUIRE(E >= 0, GSAT_ERR_ARG, "gsat_symmetrise: bad E");
     if (E == 0) return GSAT_OK;
     GSAT_REQUIRE(att && rev && out, GSAT_ERR_ARG, "gsat_symmetrise: null pointer");
-    k_symmetrise<<<GRID1(E)>>>(att, rev, E, out);
+    k_symmetrise<<<GRID1(E)>>>(att, rev, undirected_flag, E, out);
     GSAT_LAUNCH_CHECK();
     return GSAT_OK;
 }

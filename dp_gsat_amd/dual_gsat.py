@@ -87,6 +87,10 @@ class DualGSAT(nn.Module):
     # -- src/run_gsat.py:189-428 -----------------------------------------------------------------------------------
     def dual_forward_pass(self, primal_data, dual_data, epoch, training, primal_noise=None, dual_noise=None,
                           primal_masks=None, dual_masks=None):
+        from .graph_index import get_index
+        for d in (primal_data, dual_data):
+            if getattr(d, "num_graphs", None) is not None:      # prime the segment cache without `batch.max()` (a host sync)
+                get_index(d.edge_index, d.x.shape[0]).graphs(d.batch, int(d.num_graphs))
         primal_emb = self.primal_clf.get_emb(primal_data.x, primal_data.edge_index, batch=primal_data.batch,
                                              edge_attr=primal_data.edge_attr)
         Mp = primal_data.edge_index.shape[1] if self.primal_learn_edge_att else primal_data.x.shape[0]

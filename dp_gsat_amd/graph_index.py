@@ -17,6 +17,20 @@ from . import _lib
 from ._lib import call, ptr, stream
 
 
+# Sync-free mode: nothing in the step reads device memory back on the host (no `if is_undirected`, no hub-row count),
+# so a whole step can be captured into a hipGraph (torch.cuda.graph) and replayed; decisions move into the kernels.
+_SYNC_FREE = False
+
+
+def set_sync_free(flag: bool) -> None:
+    global _SYNC_FREE
+    _SYNC_FREE = bool(flag)
+
+
+def sync_free() -> bool:
+    return _SYNC_FREE
+
+
 def _i32(n, device):
     return torch.empty(max(int(n), 1), dtype=torch.int32, device=device)[: int(n)]
 
@@ -67,6 +81,8 @@ class BatchIndex:
         call("gsat_narrow_i64", ptr(dst.contiguous()), E, ptr(self.dst32), stream())
         self._checked = False
         self._rev = None
+        self._rev_dev = None
+        self._rev_flags = None
         self._undirected = None
         self._slot_dst_of_srcslot = None
         self._graphs = {}
@@ -76,6 +92,8 @@ class BatchIndex:
         """(by-destination, by-source) chunk lists, or (None, None) when no row has more than GSAT_LONG_ROW_EDGES
         entries -- then the aggregation calls skip the hub-chunk launch.  Costs one small read-back per index
         (per collated batch), merged with the undirected-flag read when that one is needed too."""
+        if _SYNC_FREE and self._long is None:
+            return (self.chunk_ptr_dst, self.chunk_ptr_src)            # always run the (early-exit) hub-chunk launch
         if self._long is None:
             if self.E <= 256:
                 self._long = (False, False)
@@ -109,21 +127,37 @@ class BatchIndex:
         rev = _i32(E, dev)
         flags = torch.zeros(2, dtype=torch.int32, device=dev)
         call("gsat_reverse_edge_perm", ptr(self.edge_index), E, N, ptr(rev), ptr(flags), ptr(ws), ws_bytes, stream())
+        self._rev_dev, self._rev_flags = rev, flags
+        if _SYNC_FREE:
+            return
         f = flags.tolist()                       # the reference syncs here too (python `if is_undirected`)
         self._undirected = bool(f[0])
         self._rev = rev if self._undirected else None
 
     @property
+    def rev_and_flag(self):
+        """(rev int32[E], flags int32[2]) on the device, no host read: flags[0] = 1 iff the edge set is symmetric."""
+        if self._rev_dev is None:
+            self._build_rev()
+        return self._rev_dev, self._rev_flags
+
+    @property
     def is_undirected(self) -> bool:
         if self._undirected is None:
-            self._build_rev()
+            if self._rev_dev is not None:        # built in sync-free mode: read the flag now
+                self._undirected = bool(self._rev_flags.tolist()[0])
+                self._rev = self._rev_dev if self._undirected else None
+            else:
+                self._build_rev()
+                if self._undirected is None:
+                    self._undirected = bool(self._rev_flags.tolist()[0])
+                    self._rev = self._rev_dev if self._undirected else None
         return self._undirected
 
     @property
     def rev(self) -> Optional[torch.Tensor]:
         """int32[E] reverse-edge permutation, or None when the edge set is not symmetric."""
-        if self._undirected is None:
-            self._build_rev()
+        self.is_undirected
         return self._rev
 
     @property

@@ -12,7 +12,7 @@ import torch
 import torch.nn as nn
 
 from .get_model import MLP
-from .graph_index import get_index
+from .graph_index import get_index, sync_free
 from .ops import ExtractorAttention, InfoLoss, Lift, Sample, Symmetrise, new_seed
 
 
@@ -60,10 +60,16 @@ class ExtractorMLP(nn.Module):
         segments = index.graphs(batch)
         l1, l2, l3 = self.mlp.linears()
         m1, m2 = dropout_masks if dropout_masks is not None else (None, None)
+        seed_dev = None
         if seed is None:
-            seed = new_seed() if (self.training and self.mlp.dropout_p > 0 and m1 is None) else 0
+            need = self.training and self.mlp.dropout_p > 0 and m1 is None
+            if need and sync_free():
+                # graph-capturable: the seed lives on the device and is redrawn by a graph-safe RNG op on every replay
+                seed, seed_dev = 0, torch.empty(1, dtype=torch.int64, device=emb.device).random_()
+            else:
+                seed = new_seed() if need else 0
         return ExtractorAttention.apply(emb, l1.weight, l1.bias, l2.weight, l2.bias, l3.weight, l3.bias, index, segments,
-                                        self.edge_mode, self.training, self.mlp.dropout_p, seed, m1, m2, noise)
+                                        self.edge_mode, self.training, self.mlp.dropout_p, seed, m1, m2, noise, seed_dev)
 
     def forward(self, emb, edge_index, batch, type: Optional[str] = None, dropout_masks=None):
         if type is not None and self.type is not None and type != self.type:
@@ -103,6 +109,9 @@ def lift_node_att_to_edge_att(node_att, edge_index):
 def symmetrise_edge_att(att, edge_index, num_nodes):
     """example/gsat.py:79-85: average with the reverse edge iff the edge set is symmetric."""
     index = get_index(edge_index, num_nodes)
+    if sync_free():
+        rev, flags = index.rev_and_flag                   # the symmetric / not-symmetric decision stays on the device
+        return Symmetrise.apply(att, rev, flags)
     if index.is_undirected:
         return Symmetrise.apply(att, index.rev)
     return att
@@ -145,6 +154,9 @@ class GSAT(nn.Module):
         """Returns (edge_att, loss, loss_dict, clf_logits) like the reference.  ``noise`` / ``dropout_masks``
         optionally pin the randomness (same-seed parity is impossible against torch's CPU generator)."""
         N = data.x.shape[0]
+        num_graphs = getattr(data, "num_graphs", None)
+        if num_graphs is not None:      # PyG batches know their graph count: prime the segment cache without `batch.max()` (a sync)
+            get_index(data.edge_index, N).graphs(data.batch, int(num_graphs))
         emb = self.clf.get_emb(data.x, data.edge_index, batch=data.batch, edge_attr=data.edge_attr)
         if training and noise is None:
             M = data.edge_index.shape[1] if self.learn_edge_att else N

@@ -175,7 +175,7 @@ def pna_aggregate(x, index, att, edge_emb, aggregators, scalers, avg_deg):
 # ------------------------------------------------------------------------------------------------
 # attention extractor MLP (+ fused concrete sampler)
 # ------------------------------------------------------------------------------------------------
-def _attn_args(emb, params, index, segments, edge_mode, training, p, seed, mask1, mask2, u, bufs):
+def _attn_args(emb, params, index, segments, edge_mode, training, p, seed, mask1, mask2, u, bufs, seed_dev=None):
     from ._lib import AttnArgs
     W1, b1, W2, b2, W3, b3 = params
     N, H = emb.shape
@@ -194,6 +194,7 @@ def _attn_args(emb, params, index, segments, edge_mode, training, p, seed, mask1
     a.emb, a.mask1, a.mask2, a.u = ptr(emb), ptr(mask1), ptr(mask2), ptr(u)
     P, Q, a1, h2, stats, logits, att = bufs
     a.P, a.Q, a.a1, a.h2, a.stats, a.logits, a.att = ptr(P), ptr(Q), ptr(a1), ptr(h2), ptr(stats), ptr(logits), ptr(att)
+    a.seed_dev = ptr(seed_dev)
     return a
 
 
@@ -204,7 +205,7 @@ class ExtractorAttention(torch.autograd.Function):
     (example/gsat.py:94-103,131-139; src/utils/get_model.py:47-68; src/run_gsat.py:877-927)."""
 
     @staticmethod
-    def forward(ctx, emb, W1, b1, W2, b2, W3, b3, index, segments, edge_mode, training, p, seed, mask1, mask2, u):
+    def forward(ctx, emb, W1, b1, W2, b2, W3, b3, index, segments, edge_mode, training, p, seed, mask1, mask2, u, seed_dev=None):
         import ctypes
         emb = _f32c(emb)
         params = tuple(_f32c(t) for t in (W1, b1, W2, b2, W3, b3))
@@ -233,7 +234,7 @@ class ExtractorAttention(torch.autograd.Function):
         logits = torch.empty(M, 1, dtype=f32, device=dev)
         att = torch.empty(M, 1, dtype=f32, device=dev)
         bufs = (P, Q, a1, h2, stats, logits, att)
-        args = _attn_args(emb, params, index, segments, edge_mode, training, p, seed, mask1, mask2, u, bufs)
+        args = _attn_args(emb, params, index, segments, edge_mode, training, p, seed, mask1, mask2, u, bufs, seed_dev)
         from ._lib import load
         fws_bytes = int(load().gsat_attn_fwd_workspace_bytes(ctypes.byref(args)))
         if fws_bytes:
@@ -246,6 +247,7 @@ class ExtractorAttention(torch.autograd.Function):
                               u if u is not None else emb.new_empty(0))
         ctx.meta = (index, segments, bool(edge_mode), bool(training), float(p), int(seed),
                     mask1 is not None, mask2 is not None, u is not None)
+        ctx.seed_dev = seed_dev
         return logits, att
 
     @staticmethod
@@ -258,7 +260,7 @@ class ExtractorAttention(torch.autograd.Function):
         logits_dummy = att  # not read by the backward
         bufs = (P, Q if edge_mode else None, a1, h2, stats, logits_dummy, att)
         args = _attn_args(emb, params, index, segments, edge_mode, training, p, seed, mask1 if has_m1 else None,
-                          mask2 if has_m2 else None, u if has_u else None, bufs)
+                          mask2 if has_m2 else None, u if has_u else None, bufs, ctx.seed_dev)
         g = AttnGrads()
         dlogits = None if dlogits is None else _f32c(dlogits)
         datt = None if datt is None else _f32c(datt)
@@ -275,7 +277,7 @@ class ExtractorAttention(torch.autograd.Function):
         ws = torch.empty(ws_bytes, dtype=torch.uint8, device=emb.device)
         g.workspace, g.workspace_bytes = ptr(ws), ws_bytes
         call("gsat_attn_bwd", ctypes.byref(args), ctypes.byref(g), stream())
-        return (demb, *grads, None, None, None, None, None, None, None, None, None)
+        return (demb, *grads, None, None, None, None, None, None, None, None, None, None)
 
 
 def new_seed() -> int:
@@ -331,23 +333,25 @@ class Lift(torch.autograd.Function):
 
 
 class Symmetrise(torch.autograd.Function):
-    """(att + att[rev]) / 2  (example/gsat.py:81-83)."""
+    """(att + att[rev]) / 2  (example/gsat.py:81-83); with ``flag`` (device int32) the `if is_undirected` of the
+    reference is decided inside the kernel: flag[0] == 0 -> identity."""
 
     @staticmethod
-    def forward(ctx, att, rev):
+    def forward(ctx, att, rev, flag=None):
         a = _f32c(att)
         out = torch.empty_like(a)
-        call("gsat_symmetrise", ptr(a), ptr(rev), a.numel(), ptr(out), stream())
-        ctx.save_for_backward(rev)
+        call("gsat_symmetrise", ptr(a), ptr(rev), ptr(flag), a.numel(), ptr(out), stream())
+        ctx.save_for_backward(rev, flag if flag is not None else rev.new_empty(0))
+        ctx.has_flag = flag is not None
         return out
 
     @staticmethod
     def backward(ctx, dout):
-        (rev,) = ctx.saved_tensors
+        rev, flag = ctx.saved_tensors
         d = _f32c(dout)
         da = torch.empty_like(d)
-        call("gsat_symmetrise", ptr(d), ptr(rev), d.numel(), ptr(da), stream())
-        return da, None
+        call("gsat_symmetrise", ptr(d), ptr(rev), ptr(flag if ctx.has_flag else None), d.numel(), ptr(da), stream())
+        return da, None, None
 
 
 class InfoLoss(torch.autograd.Function):

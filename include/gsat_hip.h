@@ -269,6 +269,7 @@ typedef struct gsat_attn_args {
     float* att;                /* [M] out, nullable */
     void* fwd_workspace;       /* gsat_attn_fwd_workspace_bytes() bytes (0 for batches of small graphs) */
     size_t fwd_workspace_bytes;
+    const uint64_t* seed_dev;  /* nullable DEVICE word overriding `seed` (hipGraph replays: new dropout mask per replay) */
 } gsat_attn_args;
 
 typedef struct gsat_attn_grads {
@@ -331,7 +332,8 @@ int gsat_lift_bwd(const float* node_att, const float* dedge_att, const int32_t* 
  * out[k] = (att[k] + att[rev[k]]) / 2 ; rev from gsat_reverse_edge_perm (an involution, so the same
  * call maps d(out) to d(att)).  replaces: example/gsat.py:81-83, src/run_gsat.py:233-235,243-245.
  */
-int gsat_symmetrise(const float* att, const int32_t* rev, int64_t num_edges, float* out, void* stream);
+int gsat_symmetrise(const float* att, const int32_t* rev, const int32_t* undirected_flag /* nullable device int32: 0 -> out = att */,
+                    int64_t num_edges, float* out, void* stream);
 
 /*
  * out[0] = mean_m [ a log(a/r + 1e-6) + (1-a) log((1-a)/(1-r+1e-6) + 1e-6) ], r = r_vec[m] if r_vec
