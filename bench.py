@@ -211,20 +211,23 @@ def aggregation_roofline(wl, data, dev, reps=30, rounds=5):
                  N, E, H, 1.0, ptr(y), ptr(ix.long_rows[0]), ptr(ix.partial(H)) if ix.long_rows[0] is not None else None, stream())
         alg_bytes = 8 * N * H + 8 * E + 4 * N + (4 * E * H if ee is not None else 0)   # SURVEY 8d (+ edge_emb read for GINE)
         kname = "k_aggr_sum_fwd"
-    for _ in range(5):
-        launch()
-    torch.cuda.synchronize(dev)
-    best = []
-    for _ in range(rounds):
-        start, end = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        torch.cuda._sleep(4_000_000)              # keep the queue busy so the launches below run back to back
-        start.record()
-        for _ in range(reps):
-            launch()
-        end.record()
+    def time_launches(fn):
+        for _ in range(5):
+            fn()
         torch.cuda.synchronize(dev)
-        best.append(start.elapsed_time(end) * 1e-3 / reps)
-    t = float(np.median(best))
+        ts = []
+        for _ in range(rounds):
+            start, end = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            torch.cuda._sleep(4_000_000)              # keep the queue busy so the launches below run back to back
+            start.record()
+            for _ in range(reps):
+                fn()
+            end.record()
+            torch.cuda.synchronize(dev)
+            ts.append(start.elapsed_time(end) * 1e-3 / reps)
+        return float(np.median(ts))
+
+    t = time_launches(launch)
     achieved = alg_bytes / t / 1e9
     traffic = None          # HBM bytes per launch from rocprofv3 PMC passes (offline, profiles/pmc_traffic.json), same shape only
     try:
@@ -233,9 +236,32 @@ def aggregation_roofline(wl, data, dev, reps=30, rounds=5):
             traffic = rec["traffic_bytes_per_launch"]
     except (OSError, ValueError, KeyError):
         pass
-    return dict(bound="hbm", kernel=kname, achieved=round(achieved, 1), peak=HBM_PEAK_GBS, unit="GB/s",
-                frac=round(achieved / HBM_PEAK_GBS, 4), traffic=traffic, alg_bytes_per_launch=int(alg_bytes),
-                us_per_launch=round(t * 1e6, 2), nodes=N, edges=E)
+    out = dict(bound="hbm", kernel=kname, achieved=round(achieved, 1), peak=HBM_PEAK_GBS, unit="GB/s",
+               frac=round(achieved / HBM_PEAK_GBS, 4), traffic=traffic, alg_bytes_per_launch=int(alg_bytes),
+               us_per_launch=round(t * 1e6, 2), nodes=N, edges=E)
+    # the backward of the same aggregation (by time the largest kernel of the step), priced the same way
+    if wl["backbone"] == "PNA":
+        dout = torch.randn(N, S * A * 2 * H, device=dev)
+        dx_self, dmsg, datt = torch.empty(N, H, device=dev), torch.empty(E, H, device=dev), torch.empty(E, device=dev)
+        def launch_bwd():
+            call("gsat_pna_bwd", ptr(x), ptr(att), None, ptr(dout), ptr(ix.rowptr_dst), ptr(ix.src_by_dst), ptr(ix.eid_by_dst), N, H,
+                 a_arr, A, s_arr, S, 1.0, 1.0, ptr(dx_self), ptr(dmsg), ptr(datt), None, stream())
+        bwd_bytes = 4 * S * A * 2 * N * H + 4 * N * H + 4 * N * H + 4 * E * H + 16 * E + 4 * N   # dout, x, dx_self, dmsg, att/datt/col/eid, rowptr
+        bname = "k_pna_bwd_dst"
+    else:
+        dout = torch.randn(N, H, device=dev)
+        dx, datt = torch.empty(N, H, device=dev), torch.empty(E, device=dev)
+        dee = torch.empty(E, H, device=dev) if data.edge_attr is not None else None
+        def launch_bwd():
+            call("gsat_aggr_sum_bwd", ptr(x), ptr(att), ptr(ee), ptr(dout), ptr(ix.rowptr_src), ptr(ix.dst_by_src), ptr(ix.eid_by_src),
+                 N, E, H, 1.0, ptr(dx), ptr(datt), ptr(dee), ptr(ix.long_rows[1]),
+                 ptr(ix.partial(H)) if ix.long_rows[1] is not None else None, stream())
+        bwd_bytes = 12 * N * H + 16 * E + 8 * N + (8 * E * H if ee is not None else 0)            # SURVEY 8d (+ edge_emb read, dedge write)
+        bname = "k_aggr_sum_bwd"
+    tb = time_launches(launch_bwd)
+    out["backward"] = dict(kernel=bname, achieved=round(bwd_bytes / tb / 1e9, 1), frac=round(bwd_bytes / tb / 1e9 / HBM_PEAK_GBS, 4),
+                           alg_bytes_per_launch=int(bwd_bytes), us_per_launch=round(tb * 1e6, 2))
+    return out
 
 
 # ------------------------------------------------------------------------------------------------

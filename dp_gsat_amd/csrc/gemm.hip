@@ -14,12 +14,13 @@
 // Weight gradients reduce over the row dimension (K = #rows, huge; M x N small): blockIdx.z splits K and
 // writes partial slabs that a second kernel sums in slab order (deterministic, no atomics).
 #include "common.h"
+#include <cstdlib>
 
 namespace gsat {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
-constexpr int GM = 128, GK = 32, GT = 256;      // block tile GM x (64*TN) x GK, TN = 1 | 2
+constexpr int GK = 32, GT = 256;      // block tile (64*TM) x (64*TN) x GK, TM, TN = 1 | 2; 4 waves as 2 x 2
 constexpr int LD_KC = 129;   // k-contiguous source: transposing scalar stores, odd stride -> conflict-free
 constexpr int LD_KM = 132;   // k-major source: 16-byte vector stores need a multiple of 4
 
@@ -66,21 +67,24 @@ __device__ __forceinline__ void store_kmajor(const StageKC& s, float* __restrict
     for (int p = 0; p < GK / KPP; ++p) st4(L + (t / QPR + KPP * p) * LD_KM + cq, s.v[p]);
 }
 
-template <bool A_T, bool B_T, int TN>
+template <bool A_T, bool B_T, int TM, int TN>
 __global__ __launch_bounds__(GT) void k_gemm_f32(const float* __restrict__ A, int64_t lda, const float* __restrict__ B, int64_t ldb,
                                                  float* __restrict__ C, int64_t ldc, int M, int N, int K, int k_per_split,
                                                  const float* __restrict__ bias, int accumulate, size_t slab_stride) {
-    constexpr int GN = 64 * TN;
+    constexpr int GM = 64 * TM, GN = 64 * TN;
     constexpr int LDA = A_T ? LD_KM : LD_KC, LDB = B_T ? LD_KC : LD_KM;
-    __shared__ __attribute__((aligned(16))) float As[GK * LDA];
-    __shared__ __attribute__((aligned(16))) float Bs[GK * LDB];
+    constexpr int EP_LD = 36;                                // epilogue staging: 32 x 32 tile per wave, padded rows (16-B aligned)
+    static_assert(GK * LDA + GK * LDB >= 4 * 32 * EP_LD, "epilogue staging must fit in the operand images");
+    __shared__ __attribute__((aligned(16))) float lds[GK * LDA + GK * LDB];
+    float* const As = lds;
+    float* const Bs = lds + GK * LDA;
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
     const int wm = wave >> 1, wn = wave & 1;
     const int m0 = blockIdx.y * GM, n0 = blockIdx.x * GN;
     const int kbeg = blockIdx.z * k_per_split, kend = min(K, kbeg + k_per_split);
-    f32x16 acc[2][TN];
+    f32x16 acc[TM][TN];
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+    for (int i = 0; i < TM; ++i)
 #pragma unroll
         for (int j = 0; j < TN; ++j)
 #pragma unroll
@@ -100,45 +104,63 @@ __global__ __launch_bounds__(GT) void k_gemm_f32(const float* __restrict__ A, in
         lstore();
     }
     __syncthreads();
-    const int arow = wm * 64 + (lane & 31), bcol = wn * 32 * TN + (lane & 31), kh = lane >> 5;
+    const int arow = wm * 32 * TM + (lane & 31), bcol = wn * 32 * TN + (lane & 31), kh = lane >> 5;
     for (int k0 = kbeg; k0 < kend; k0 += GK) {
         const bool more = k0 + GK < kend;
         if (more) gload(k0 + GK);                       // next slab's global loads fly under this slab's MFMAs
 #pragma unroll
         for (int kk = 0; kk < GK / 2; ++kk) {
             const int ka = (2 * kk + kh) * LDA, kb = (2 * kk + kh) * LDB;
-            const float a0 = As[ka + arow], a1 = As[ka + arow + 32];
-            float b[TN];
+            float a[TM], b[TN];
+#pragma unroll
+            for (int i = 0; i < TM; ++i) a[i] = As[ka + arow + 32 * i];
 #pragma unroll
             for (int j = 0; j < TN; ++j) b[j] = Bs[kb + bcol + 32 * j];
 #pragma unroll
-            for (int j = 0; j < TN; ++j) {
-                acc[0][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b[j], acc[0][j], 0, 0, 0);
-                acc[1][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b[j], acc[1][j], 0, 0, 0);
-            }
+            for (int j = 0; j < TN; ++j)
+#pragma unroll
+                for (int i = 0; i < TM; ++i) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], b[j], acc[i][j], 0, 0, 0);
         }
         __syncthreads();                                // every wave is done reading this slab
         if (more) lstore();
         __syncthreads();
     }
-    // ---- epilogue: C/D map of the 32x32 MFMA: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5) ----------
+    // ---- epilogue -----------------------------------------------------------------------------------------------
+    // C/D map of the 32x32 MFMA: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5): a lane holds ONE column, so storing
+    // straight from registers is 4 bytes per lane per instruction.  Each 32x32 tile goes through a per-wave LDS patch
+    // instead and leaves as 16-byte row segments (4 store instructions per tile instead of 16).
     float* Cb = C + (size_t)blockIdx.z * slab_stride;
+    float* patch = lds + wave * (32 * EP_LD);               // all waves passed the loop's final barrier: As/Bs are free
+    const int prow = lane >> 3, pcol = (lane & 7) * 4;      // read-back: 8 lanes per row, 8 rows per pass
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+    for (int i = 0; i < TM; ++i)
 #pragma unroll
         for (int j = 0; j < TN; ++j) {
-            const int col = n0 + wn * 32 * TN + j * 32 + (lane & 31);
-            if (col >= N) continue;
-            const float bv = bias ? bias[col] : 0.f;
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int row = m0 + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * kh;
-                if (row < M) {
-                    float* p = Cb + (size_t)row * ldc + col;
-                    float v = acc[i][j][r] + bv;
-                    *p = accumulate ? *p + v : v;
+            for (int r = 0; r < 16; ++r) patch[((r & 3) + 8 * (r >> 2) + 4 * kh) * EP_LD + (lane & 31)] = acc[i][j][r];
+            __builtin_amdgcn_wave_barrier();
+            const int col = n0 + wn * 32 * TN + j * 32 + pcol;
+            float4 bv = f4zero();
+            if (bias && col + 3 < N) bv = ld4(bias + col);
+            else if (bias && col < N) { bv.x = bias[col]; if (col + 1 < N) bv.y = bias[col + 1]; if (col + 2 < N) bv.z = bias[col + 2]; }
+#pragma unroll
+            for (int p = 0; p < 4; ++p) {
+                const int rr = prow + 8 * p;
+                const int row = m0 + wm * 32 * TM + i * 32 + rr;
+                float4 v = ld4(patch + rr * EP_LD + pcol);
+                if (row < M && col < N) {
+                    float* dst = Cb + (size_t)row * ldc + col;
+                    v = make_float4(v.x + bv.x, v.y + bv.y, v.z + bv.z, v.w + bv.w);
+                    if (col + 3 < N) {
+                        if (accumulate) { float4 o = ld4(dst); v = make_float4(v.x + o.x, v.y + o.y, v.z + o.z, v.w + o.w); }
+                        st4(dst, v);
+                    } else {                                 // ragged right edge (N % 4 != 0 only for k-contiguous B)
+                        const float e[4] = {v.x, v.y, v.z, v.w};
+                        for (int q = 0; q < 4 && col + q < N; ++q) dst[q] = accumulate ? dst[q] + e[q] : e[q];
+                    }
                 }
             }
+            __builtin_amdgcn_wave_barrier();
         }
 }
 
@@ -162,19 +184,22 @@ __global__ void k_slab_reduce(const float* __restrict__ slabs, int nslab, size_t
     *p = accumulate ? *p + acc : acc;
 }
 
-// Tile choice: 128x128 blocks (3 resident per CU) unless the grid quantises badly on 256 CUs, then 128x64 blocks
-// (half the work each, 4 resident per CU).  cost ~ rounds x work per block.
-static int gemm_tn(int64_t M, int64_t N) {
-    if (N <= 64) return 1;
-    const int64_t b2 = ceil_div(M, GM) * ceil_div(N, 128), b1 = ceil_div(M, GM) * ceil_div(N, 64);
+// Tile choice: (64*TM) x (64*TN).  128x128 for big outputs, 128x64 when that quantises better on 256 CUs, 64x64 for the
+// short-K tall-skinny products of the node-mode extractor (more, lighter blocks hide the per-block load latency).
+static void gemm_tile(int64_t M, int64_t N, int64_t K, int* tm, int* tn) {
+    if (const char* e = getenv("GSAT_GEMM_TILE")) { int v = atoi(e); *tm = v / 10 == 2 ? 2 : 1; *tn = v % 10 == 2 ? 2 : 1; return; }   // tuning override "TMTN"
+    *tm = 2;
+    if (N <= 64) { *tn = 1; return; }
+    const int64_t b2 = ceil_div(M, 128) * ceil_div(N, 128), b1 = ceil_div(M, 128) * ceil_div(N, 64);
     const int64_t cost2 = ceil_div(b2, 256 * 3) * 2, cost1 = ceil_div(b1, 256 * 4) * 1;
-    return cost1 < cost2 ? 1 : 2;
+    *tn = cost1 < cost2 ? 1 : 2;
+    (void)K;
 }
 
 // number of K splits used for an M x N output reduced over K rows (shared by the workspace query)
 int gemm_splits(int64_t M, int64_t N, int64_t K, bool reduce_rows) {
     if (!reduce_rows) return 1;                       // only weight gradients (K = #rows) are split
-    const int64_t tiles = ceil_div(M, GM) * ceil_div(N, 128);
+    const int64_t tiles = ceil_div(M, 128) * ceil_div(N, 128);
     if (tiles >= 256 || K <= 4 * GK) return 1;
     int64_t s = std::min<int64_t>(ceil_div(768, tiles), ceil_div(K, 8 * GK));
     return (int)std::max<int64_t>(1, std::min<int64_t>(s, 512));
@@ -193,10 +218,12 @@ int gemm_f32(hipStream_t stream, bool a_t, bool b_t, int64_t M, int64_t N, int64
     GSAT_REQUIRE(K > 0 && A && B && C, GSAT_ERR_ARG, "gemm_f32: bad argument");
     GSAT_REQUIRE(lda % 4 == 0 && ldb % 4 == 0 && (a_t ? M % 4 == 0 : K % 4 == 0) && (b_t ? K % 4 == 0 : N % 4 == 0), GSAT_ERR_UNSUPPORTED,
                  "gemm_f32: contiguous extents and leading dimensions must be multiples of 4 (M=%lld N=%lld K=%lld)", (long long)M, (long long)N, (long long)K);
-    GSAT_REQUIRE(((uintptr_t)A % 16 == 0) && ((uintptr_t)B % 16 == 0), GSAT_ERR_ARG, "gemm_f32: operands must be 16-byte aligned");
+    GSAT_REQUIRE(((uintptr_t)A % 16 == 0) && ((uintptr_t)B % 16 == 0) && ((uintptr_t)C % 16 == 0) && ldc % 4 == 0 && (!bias || (uintptr_t)bias % 16 == 0),
+                 GSAT_ERR_ARG, "gemm_f32: operands, output and bias must be 16-byte aligned with ldc % 4 == 0");
     const int splits = gemm_splits(M, N, K, a_t);
-    const int tn = splits > 1 ? 2 : gemm_tn(M, N);
-    dim3 grid((unsigned)ceil_div(N, 64 * tn), (unsigned)ceil_div(M, GM), (unsigned)splits);
+    int tm = 2, tn = 2;
+    if (splits == 1) gemm_tile(M, N, K, &tm, &tn);
+    dim3 grid((unsigned)ceil_div(N, 64 * tn), (unsigned)ceil_div(M, 64 * tm), (unsigned)splits);
     int kps = (int)(ceil_div(ceil_div(K, splits), GK) * GK);
     float* out = C;
     int64_t ldo = ldc;
@@ -210,8 +237,10 @@ int gemm_f32(hipStream_t stream, bool a_t, bool b_t, int64_t M, int64_t N, int64
     }
 #define LAUNCH(AT, BT)                                                                                                              \
     do {                                                                                                                            \
-        if (tn == 2) k_gemm_f32<AT, BT, 2><<<grid, GT, 0, stream>>>(A, lda, B, ldb, out, ldo, (int)M, (int)N, (int)K, kps, bptr, acc_flag, slab); \
-        else k_gemm_f32<AT, BT, 1><<<grid, GT, 0, stream>>>(A, lda, B, ldb, out, ldo, (int)M, (int)N, (int)K, kps, bptr, acc_flag, slab);         \
+        if (tm == 2 && tn == 2) k_gemm_f32<AT, BT, 2, 2><<<grid, GT, 0, stream>>>(A, lda, B, ldb, out, ldo, (int)M, (int)N, (int)K, kps, bptr, acc_flag, slab); \
+        else if (tm == 2) k_gemm_f32<AT, BT, 2, 1><<<grid, GT, 0, stream>>>(A, lda, B, ldb, out, ldo, (int)M, (int)N, (int)K, kps, bptr, acc_flag, slab);       \
+        else if (tn == 2) k_gemm_f32<AT, BT, 1, 2><<<grid, GT, 0, stream>>>(A, lda, B, ldb, out, ldo, (int)M, (int)N, (int)K, kps, bptr, acc_flag, slab);       \
+        else k_gemm_f32<AT, BT, 1, 1><<<grid, GT, 0, stream>>>(A, lda, B, ldb, out, ldo, (int)M, (int)N, (int)K, kps, bptr, acc_flag, slab);                    \
     } while (0)
     if (a_t) { if (b_t) LAUNCH(true, true); else LAUNCH(true, false); }
     else { if (b_t) LAUNCH(false, true); else LAUNCH(false, false); }
