@@ -40,6 +40,7 @@ SIGNATURES = {
     "gsat_onehot_rows": (INT, [P, P, INT, I64, I64, P, P]),
     "gsat_gemm_workspace_floats": (SZ, [INT, I64, I64, I64]),
     "gsat_gemm_f32": (INT, [INT, INT, I64, I64, I64, P, I64, P, I64, P, I64, P, INT, P, SZ, P]),
+    "gsat_gemm_bf16x3": (INT, [INT, INT, I64, I64, I64, P, I64, P, I64, P, I64, P, INT, P, SZ, P]),
     "gsat_attn_fwd_workspace_bytes": (SZ, [P]),
     "gsat_attn_bwd_workspace_bytes": (SZ, [P]),
     "gsat_attn_fwd": (INT, [P, P]),

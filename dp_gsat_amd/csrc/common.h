@@ -53,7 +53,7 @@ struct Arena {
 
 // ---- fp32 MFMA GEMM (gemm.hip): C[M,N] (+)= op(A) op(B) (+ bias) --------------------------------
 int gemm_f32(hipStream_t stream, bool a_t, bool b_t, int64_t M, int64_t N, int64_t K, const float* A, int64_t lda, const float* B,
-             int64_t ldb, float* C, int64_t ldc, const float* bias, bool accumulate, float* ws, size_t ws_floats);
+             int64_t ldb, float* C, int64_t ldc, const float* bias, bool accumulate, float* ws, size_t ws_floats, bool allow_split = false);
 size_t gemm_workspace_floats(int64_t M, int64_t N, int64_t K, bool reduce_rows);
 
 // ---- gather-sum over a CSR (aggregate.hip), reused by the extractor backward -------------------------

@@ -478,32 +478,54 @@ class BatchNormFn(torch.autograd.Function):
         return dx, dgamma, dbeta, None, None, None, None, None, None
 
 
+def _gemm(a_t, b_t, M, N, K, A, lda, B, ldb, C, ldc, bias=None, split=True):
+    from ._lib import load
+    wsf = int(load().gsat_gemm_workspace_floats(int(a_t), M, N, K))
+    ws = torch.empty(wsf, dtype=torch.float32, device=C.device) if wsf else None
+    call("gsat_gemm_bf16x3" if split else "gsat_gemm_f32", int(a_t), int(b_t), M, N, K, ptr(A), lda, ptr(B), ldb, ptr(C), ldc,
+         ptr(bias), 0, ptr(ws), wsf, stream())
+
+
+# Linear products above this many FLOPs run on the split-bf16 MFMA path (gsat_gemm_bf16x3: 2-3x the fp32 library GEMM at the
+# backbone's shapes); smaller ones stay on the library (hipBLASLt via torch), which is as fast there
+_OWN_GEMM_FLOPS = 2e9
+
+
 class LinearFn(torch.autograd.Function):
-    """y = x W^T + b for tall-skinny x.  Forward and dx are plain library GEMMs (torch -> hipBLASLt, already near
-    roofline here); the weight gradient dW = dy^T x reduces over the ~1e5 node rows into a tiny [out, in] matrix, where
-    the library picks a non-split kernel (308 us at C3) -- it goes through the hand-written split-K MFMA GEMM."""
+    """y = x W^T + b for tall-skinny x (node / edge rows).  Large products -- forward, dx and the weight gradient, which
+    reduces over ~1e5 rows into a tiny [out, in] matrix -- run on the hand-written MFMA GEMM; small ones on the library."""
 
     @staticmethod
     def forward(ctx, x, weight, bias):
         x, weight = _f32c(x), _f32c(weight)
-        y = torch.nn.functional.linear(x, weight, bias)
+        M, K = x.shape
+        N = weight.shape[0]
+        if 2.0 * M * N * K >= _OWN_GEMM_FLOPS and (bias is None or bias.data_ptr() % 16 == 0):
+            y = torch.empty(M, N, dtype=torch.float32, device=x.device)
+            _gemm(0, 1, M, N, K, x, K, weight, K, y, N, None if bias is None else _f32c(bias))
+        else:
+            y = torch.nn.functional.linear(x, weight, bias)
         ctx.save_for_backward(x, weight)
         ctx.has_bias = bias is not None
         return y
 
     @staticmethod
     def backward(ctx, dy):
-        from ._lib import load
         x, weight = ctx.saved_tensors
         dy = _f32c(dy)
-        dx = dy @ weight if ctx.needs_input_grad[0] else None
+        rows, n_out, n_in = x.shape[0], weight.shape[0], weight.shape[1]
+        big = 2.0 * rows * n_out * n_in >= _OWN_GEMM_FLOPS
+        dx = None
+        if ctx.needs_input_grad[0]:
+            if big:
+                dx = torch.empty_like(x)
+                _gemm(0, 0, rows, n_in, n_out, dy, n_out, weight, n_in, dx, n_in)
+            else:
+                dx = dy @ weight
         dw = None
         if ctx.needs_input_grad[1]:
-            rows, n_out, n_in = x.shape[0], weight.shape[0], weight.shape[1]
             dw = torch.empty_like(weight)
-            wsf = int(load().gsat_gemm_workspace_floats(1, n_out, n_in, rows))
-            ws = torch.empty(max(wsf, 1), dtype=torch.float32, device=x.device)
-            call("gsat_gemm_f32", 1, 0, n_out, n_in, rows, ptr(dy), n_out, ptr(x), n_in, ptr(dw), n_in, None, 0, ptr(ws), wsf, stream())
+            _gemm(1, 0, n_out, n_in, rows, dy, n_out, x, n_in, dw, n_in, split=big)
         db = dy.sum(0) if ctx.has_bias and ctx.needs_input_grad[2] else None
         return dx, dw, db
 

@@ -224,6 +224,14 @@ size_t gsat_gemm_workspace_floats(int a_t, int64_t M, int64_t N, int64_t K);
 int gsat_gemm_f32(int a_t, int b_t, int64_t M, int64_t N, int64_t K, const float* A, int64_t lda,
                   const float* B, int64_t ldb, float* C, int64_t ldc, const float* bias, int accumulate,
                   float* workspace, size_t workspace_floats, void* stream);
+/*
+ * Same contract, but products of >= 2 GFLOP run as split-bf16: every fp32 operand x = hi + lo (two bf16), the product is
+ * hi*hi + hi*lo + lo*hi accumulated in fp32 on v_mfma_f32_32x32x16_bf16 (relative error ~1e-5 of |A||B|, 2-5x faster).
+ * For callers whose outputs are not re-normalised by a small per-graph sigma (the backbone's Linear layers).
+ */
+int gsat_gemm_bf16x3(int a_t, int b_t, int64_t M, int64_t N, int64_t K, const float* A, int64_t lda,
+                     const float* B, int64_t ldb, float* C, int64_t ldc, const float* bias, int accumulate,
+                     float* workspace, size_t workspace_floats, void* stream);
 
 /* =============================== attention extractor MLP ===================================== */
 
