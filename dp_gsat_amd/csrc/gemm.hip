@@ -198,35 +198,38 @@ __device__ __forceinline__ void store_split_kcontig(const StageKC& s, unsigned c
         *reinterpret_cast<uint2*>(lo + r * BRS + kq * 2) = L;
     }
 }
-// k-major source X[k][c]: work item w -> column quad w % (COLS/4), k-pair w / (COLS/4); two float4 (rows 2kp, 2kp+1)
-struct StageKM { float4 v[2][2]; };
+// k-major source X[k][c] (weight-gradient operands, W of the dx product): the LDS image is [k/8][col][8 bf16], so a lane
+// that owns 8 consecutive k of one column writes one 16-byte chunk and consecutive lanes write consecutive chunks
+// (conflict-free ds_write_b128), while the MFMA operand fetch of lane (r, h) at step ks is chunk (2 ks + h) of column r:
+// again consecutive lanes, consecutive 16 bytes.  Work item = 8 k x 2 columns: 8 coalesced float2 loads.
+struct StageKM { float2 v[8]; };
 template <int COLS>
 __device__ __forceinline__ void load_split_kmajor(StageKM& s, const float* __restrict__ X, int64_t ld, int c0, int Ccols, int k0, int K, int t) {
-    constexpr int QPR = COLS / 4, ITEMS = QPR * 16 / GT;      // 2 for COLS = 128, 1 for COLS = 64
+    constexpr int PAIRS = COLS / 2;                       // 64 (COLS = 128) or 32 (COLS = 64) column pairs x 4 k-octets
+    if (t >= PAIRS * 4) return;
+    const int cp = (t % PAIRS) * 2, k8 = t / PAIRS;
 #pragma unroll
-    for (int it = 0; it < ITEMS; ++it) {
-        const int w = t + it * GT, cq = (w % QPR) * 4, kp = w / QPR;
-#pragma unroll
-        for (int h = 0; h < 2; ++h) {
-            const int k = k0 + 2 * kp + h;
-            s.v[it][h] = (k < K && c0 + cq < Ccols) ? ld4(X + (size_t)k * ld + c0 + cq) : f4zero();
-        }
+    for (int j = 0; j < 8; ++j) {
+        const int k = k0 + k8 * 8 + j;
+        s.v[j] = (k < K && c0 + cp < Ccols) ? *reinterpret_cast<const float2*>(X + (size_t)k * ld + c0 + cp) : make_float2(0.f, 0.f);
     }
 }
 template <int COLS>
 __device__ __forceinline__ void store_split_kmajor(const StageKM& s, unsigned char* __restrict__ hi, unsigned char* __restrict__ lo, int t) {
-    constexpr int QPR = COLS / 4, ITEMS = QPR * 16 / GT;
+    constexpr int PAIRS = COLS / 2;
+    if (t >= PAIRS * 4) return;
+    const int cp = (t % PAIRS) * 2, k8 = t / PAIRS;
 #pragma unroll
-    for (int it = 0; it < ITEMS; ++it) {
-        const int w = t + it * GT, cq = (w % QPR) * 4, kp = w / QPR;
-        const float a[4] = {s.v[it][0].x, s.v[it][0].y, s.v[it][0].z, s.v[it][0].w};
-        const float b[4] = {s.v[it][1].x, s.v[it][1].y, s.v[it][1].z, s.v[it][1].w};
+    for (int c = 0; c < 2; ++c) {
+        float x[8];
 #pragma unroll
-        for (int c = 0; c < 4; ++c) {
-            const float ha = bf16_hi(a[c]), hb = bf16_hi(b[c]);
-            *reinterpret_cast<unsigned*>(hi + (cq + c) * BRS + kp * 4) = pack_bf16(a[c], b[c]);
-            *reinterpret_cast<unsigned*>(lo + (cq + c) * BRS + kp * 4) = pack_bf16(a[c] - ha, b[c] - hb);
-        }
+        for (int j = 0; j < 8; ++j) x[j] = c == 0 ? s.v[j].x : s.v[j].y;
+        uint4 H = make_uint4(pack_bf16(x[0], x[1]), pack_bf16(x[2], x[3]), pack_bf16(x[4], x[5]), pack_bf16(x[6], x[7]));
+        uint4 L = make_uint4(pack_bf16(x[0] - bf16_hi(x[0]), x[1] - bf16_hi(x[1])), pack_bf16(x[2] - bf16_hi(x[2]), x[3] - bf16_hi(x[3])),
+                             pack_bf16(x[4] - bf16_hi(x[4]), x[5] - bf16_hi(x[5])), pack_bf16(x[6] - bf16_hi(x[6]), x[7] - bf16_hi(x[7])));
+        const int off = (k8 * COLS + cp + c) * 16;
+        *reinterpret_cast<uint4*>(hi + off) = H;
+        *reinterpret_cast<uint4*>(lo + off) = L;
     }
 }
 
@@ -271,7 +274,9 @@ __global__ __launch_bounds__(GT) void k_gemm_bf16x3(const float* __restrict__ A,
     }
     __syncthreads();
     const int r32 = lane & 31, kh = lane >> 5;
-    const int aoff = (wm * 32 * TM + r32) * BRS + kh * 16, boff = (wn * 32 * TN + r32) * BRS + kh * 16;
+    // byte offset of the 16-byte operand chunk of (tile row/col `rc`, MFMA step ks): [row][k] image vs [k/8][col][8] image
+    auto a_chunk = [&](int i, int ks) { const int rc = wm * 32 * TM + 32 * i + r32; return A_T ? ((2 * ks + kh) * GM + rc) * 16 : rc * BRS + ks * 32 + kh * 16; };
+    auto b_chunk = [&](int j, int ks) { const int rc = wn * 32 * TN + 32 * j + r32; return B_T ? rc * BRS + ks * 32 + kh * 16 : ((2 * ks + kh) * GN + rc) * 16; };
     for (int k0 = kbeg; k0 < kend; k0 += GK) {
         const bool more = k0 + GK < kend;
         if (more) gload(k0 + GK);
@@ -280,13 +285,13 @@ __global__ __launch_bounds__(GT) void k_gemm_bf16x3(const float* __restrict__ A,
             bf16x8 ah[TM], al[TM], bh[TN], bl[TN];
 #pragma unroll
             for (int i = 0; i < TM; ++i) {
-                ah[i] = *reinterpret_cast<const bf16x8*>(Ahi + aoff + i * 32 * BRS + ks * 32);
-                al[i] = *reinterpret_cast<const bf16x8*>(Alo + aoff + i * 32 * BRS + ks * 32);
+                ah[i] = *reinterpret_cast<const bf16x8*>(Ahi + a_chunk(i, ks));
+                al[i] = *reinterpret_cast<const bf16x8*>(Alo + a_chunk(i, ks));
             }
 #pragma unroll
             for (int j = 0; j < TN; ++j) {
-                bh[j] = *reinterpret_cast<const bf16x8*>(Bhi + boff + j * 32 * BRS + ks * 32);
-                bl[j] = *reinterpret_cast<const bf16x8*>(Blo + boff + j * 32 * BRS + ks * 32);
+                bh[j] = *reinterpret_cast<const bf16x8*>(Bhi + b_chunk(j, ks));
+                bl[j] = *reinterpret_cast<const bf16x8*>(Blo + b_chunk(j, ks));
             }
 #pragma unroll
             for (int j = 0; j < TN; ++j)
