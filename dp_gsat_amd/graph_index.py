@@ -98,8 +98,7 @@ class BatchIndex:
             if self.E <= 256:
                 self._long = (False, False)
             else:
-                t = torch.stack([self.chunk_ptr_dst[-1], self.chunk_ptr_src[-1]]).tolist()
-                self._long = (t[0] > 0, t[1] > 0)
+                self._readback()
         return (self.chunk_ptr_dst if self._long[0] else None, self.chunk_ptr_src if self._long[1] else None)
 
     def partial(self, H: int) -> torch.Tensor:
@@ -115,9 +114,7 @@ class BatchIndex:
     # -- validation (one host sync, deferred until something needs a host-side decision) --------
     def check(self):
         if not self._checked:
-            if int(self._err[0].item()) != 0:
-                raise ValueError("edge_index contains node ids outside [0, num_nodes)")
-            self._checked = True
+            self._readback()
 
     # -- reverse-edge permutation / undirected flag ----------------------------------------------
     def _build_rev(self):
@@ -130,9 +127,22 @@ class BatchIndex:
         self._rev_dev, self._rev_flags = rev, flags
         if _SYNC_FREE:
             return
-        f = flags.tolist()                       # the reference syncs here too (python `if is_undirected`)
-        self._undirected = bool(f[0])
-        self._rev = rev if self._undirected else None
+        self._readback()                         # the reference syncs here too (python `if is_undirected`)
+
+    def _readback(self):
+        """ONE device->host read for every host-side decision of this batch: undirected flag (if the reverse permutation
+        was built), hub-row chunk totals of both CSRs, out-of-range counter."""
+        parts = [self.chunk_ptr_dst[-1:], self.chunk_ptr_src[-1:], self._err[:1]]
+        if self._rev_flags is not None:
+            parts.append(self._rev_flags[:1])
+        vals = torch.cat(parts).tolist()
+        self._long = (vals[0] > 0, vals[1] > 0)
+        if vals[2] != 0:
+            raise ValueError("edge_index contains node ids outside [0, num_nodes)")
+        self._checked = True
+        if self._rev_flags is not None:
+            self._undirected = bool(vals[3])
+            self._rev = self._rev_dev if self._undirected else None
 
     @property
     def rev_and_flag(self):
@@ -144,14 +154,10 @@ class BatchIndex:
     @property
     def is_undirected(self) -> bool:
         if self._undirected is None:
-            if self._rev_dev is not None:        # built in sync-free mode: read the flag now
-                self._undirected = bool(self._rev_flags.tolist()[0])
-                self._rev = self._rev_dev if self._undirected else None
-            else:
+            if self._rev_dev is None:
                 self._build_rev()
-                if self._undirected is None:
-                    self._undirected = bool(self._rev_flags.tolist()[0])
-                    self._rev = self._rev_dev if self._undirected else None
+            if self._undirected is None:         # built in sync-free mode earlier: read the flag now
+                self._readback()
         return self._undirected
 
     @property
