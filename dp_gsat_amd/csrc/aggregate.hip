@@ -440,7 +440,7 @@ int aggr_sum_fwd_impl(hipStream_t stream, const float* x, const float* self_rows
     if (N == 0) return GSAT_OK;
     RowGeom g;
     GSAT_REQUIRE(row_geom(H, &g), GSAT_ERR_UNSUPPORTED, "gsat_aggr_sum_fwd: H=%lld must be a multiple of 4 and <= 2048", (long long)H);
-    GSAT_REQUIRE(x && rowptr && out && (col || E == 0), GSAT_ERR_ARG, "gsat_aggr_sum_fwd: null pointer");
+    GSAT_REQUIRE((x || (self_rows && E == 0)) && rowptr && out && (col || E == 0), GSAT_ERR_ARG, "gsat_aggr_sum_fwd: null pointer");   // an edge-row source with E == 0 rows is empty, hence NULL
     GSAT_REQUIRE((att == nullptr && edge_emb == nullptr) || eid || E == 0, GSAT_ERR_ARG, "gsat_aggr_sum_fwd: eid required with att/edge_emb");
     GSAT_REQUIRE(chunk_ptr == nullptr || partial != nullptr, GSAT_ERR_ARG, "gsat_aggr_sum_fwd: chunk_ptr needs a partial-sum workspace");
     if (E <= CH) chunk_ptr = nullptr;                      // no row can be long

@@ -109,3 +109,11 @@ def global_loss_weights(num_local_graphs: int, num_local_rows: int, device, proc
     dist.all_reduce(t, group=process_group)
     tot = t.tolist()
     return num_local_graphs / tot[0] * W, num_local_rows / tot[1] * W
+
+
+def sync_batchnorm(model: torch.nn.Module, process_group=None) -> torch.nn.Module:
+    """BatchNorm statistics over the GLOBAL batch (all ranks), so a sharded run reproduces the single-process model at the
+    same global batch (SURVEY.md 8e).  Uses torch.nn.SyncBatchNorm (one small all-reduce of (sum, sumsq, count) per layer);
+    the local HIP BatchNorm kernels are bypassed for the converted layers.  Off by default: per-rank statistics over
+    ~2k graphs are what plain DDP training uses."""
+    return torch.nn.SyncBatchNorm.convert_sync_batchnorm(model, process_group)
