@@ -349,7 +349,8 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    distributed = world > 1
+    # under torchrun (RANK set) the process group is initialised even at world size 1, so the RCCL path can be rehearsed on one GPU
+    distributed = world > 1 or ("RANK" in os.environ and "MASTER_PORT" in os.environ)
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the HIP path has no CPU fallback")
     dev = torch.device("cuda", local_rank % max(torch.cuda.device_count(), 1))
@@ -423,7 +424,7 @@ def main():
     if rank == 0:
         hot.reuse_index = True
         roof = aggregation_roofline(wl, data, dev)
-        if not args.no_cpu_baseline:
+        if not args.no_cpu_baseline and world == 1:          # reported at N=1 only
             sample = args.cpu_sample_graphs or max(1, wl["graphs"] // 8)
             cpu = cpu_baseline(wl, args.workload, args.seed, sample)
     if distributed:
