@@ -108,6 +108,8 @@ class HotPath:
             for p in self.ext.parameters():
                 p.grad = None
         self.emb.grad = None
+        for t in self.xs + (self.edge_emb or []):      # zero_grad(set_to_none=True): no accumulate-into-old-gradient adds
+            t.grad = None
         index = G.get_index(d.edge_index, self.N)
         index.graphs(d.batch, d.num_graphs)
         M = self.E if wl["edge_att"] else self.N
@@ -239,6 +241,15 @@ def aggregation_roofline(wl, data, dev, reps=30, rounds=5):
     out = dict(bound="hbm", kernel=kname, achieved=round(achieved, 1), peak=HBM_PEAK_GBS, unit="GB/s",
                frac=round(achieved / HBM_PEAK_GBS, 4), traffic=traffic, alg_bytes_per_launch=int(alg_bytes),
                us_per_launch=round(t * 1e6, 2), nodes=N, edges=E)
+    # what plain streaming passes over a buffer of the kernel's output size reach on this box (quote the vendor
+    # peak AND the measured rate): a write-only fill and a device-to-device copy (bytes = read + write)
+    y2 = torch.empty_like(y)
+    t_fill = time_launches(lambda: y.fill_(1.0))
+    t_copy = time_launches(lambda: y2.copy_(y))
+    fill_gbs, copy_gbs = y.numel() * 4 / t_fill / 1e9, 2 * y.numel() * 4 / t_copy / 1e9
+    out["measured_stream"] = dict(fill_GBps=round(fill_gbs, 1), copy_GBps=round(copy_gbs, 1), buffer_bytes=int(y.numel() * 4),
+                                  frac_of_fill=round(achieved / fill_gbs, 4), frac_of_copy=round(achieved / copy_gbs, 4))
+    del y2
     # the backward of the same aggregation (by time the largest kernel of the step), priced the same way
     if wl["backbone"] == "PNA":
         dout = torch.randn(N, S * A * 2 * H, device=dev)

@@ -152,7 +152,9 @@ __global__ __launch_bounds__(PNA_BLOCK) void k_pna_fwd(
     }
 }
 
-template <int LPR, bool HAS_EE>
+// STD4: the configuration of every PNA YAML of the reference (aggregators mean,min,max,std; scaler identity) with the
+// segment loop resolved at compile time; the generic instantiation covers every other aggregator / scaler list.
+template <int LPR, bool HAS_EE, bool STD4>
 __global__ __launch_bounds__(PNA_BLOCK, HAS_EE ? 2 : 4) void k_pna_bwd_dst(
     const float* __restrict__ x, const float* __restrict__ att, const float* __restrict__ edge_emb,
     const float* __restrict__ dout, const int32_t* __restrict__ rowptr, const int32_t* __restrict__ col,
@@ -170,7 +172,7 @@ __global__ __launch_bounds__(PNA_BLOCK, HAS_EE ? 2 : 4) void k_pna_bwd_dst(
     const int F = parts * H;
     const size_t out_stride = (size_t)cfg.S * cfg.A * F;
     const int nseg = cfg.S * cfg.A * parts;
-    const bool staged = nseg <= MAXSEG;
+    const bool staged = STD4 || nseg <= MAXSEG;
     const int wave_base = (threadIdx.x >> 6) << 6;
     const int grp = pna_xcd_remap(blockIdx.x, gridDim.x) * GPB + threadIdx.x / LPR;
     int row = grp * rows_per_group;
@@ -197,6 +199,7 @@ __global__ __launch_bounds__(PNA_BLOCK, HAS_EE ? 2 : 4) void k_pna_bwd_dst(
         const float4 xi = on ? ld4(x + (size_t)row * H + c) : f4zero();
         int lj[4] = {0, 0, 0, 0}, le[4] = {0, 0, 0, 0};      // indices / weights of the last batch: rows with <= 4 in-edges
         float lw[4] = {1.f, 1.f, 1.f, 1.f};                   // (all of a molecule graph) skip the second index + att round trip
+        float wfirst = 1.f;                                   // att of the row's first slot (arg of att*x_i where x_i == 0)
         for (int k = beg; k < end; k += 4) {
             const int nb = min(4, end - k);
             int j[4], e[4];
@@ -215,6 +218,7 @@ __global__ __launch_bounds__(PNA_BLOCK, HAS_EE ? 2 : 4) void k_pna_bwd_dst(
             }
 #pragma unroll
             for (int u = 0; u < 4; ++u) { lj[u] = j[u]; le[u] = e[u]; lw[u] = w[u]; }
+            if (k == beg) wfirst = w[0];
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
                 if (u < nb) {
@@ -238,14 +242,9 @@ __global__ __launch_bounds__(PNA_BLOCK, HAS_EE ? 2 : 4) void k_pna_bwd_dst(
             }
         }
         const Acc4 ai = self_stats(xi, sa, sa2, amin, amax);
-        // x_i part: arg of att*x_i is the arg-min/max of att by the sign of x_i (first slot when x_i == 0)
-        int4 imin, imax;
-        imin.x = xi.x > 0.f ? kmin_a : (xi.x < 0.f ? kmax_a : beg); imax.x = xi.x > 0.f ? kmax_a : (xi.x < 0.f ? kmin_a : beg);
-        imin.y = xi.y > 0.f ? kmin_a : (xi.y < 0.f ? kmax_a : beg); imax.y = xi.y > 0.f ? kmax_a : (xi.y < 0.f ? kmin_a : beg);
-        imin.z = xi.z > 0.f ? kmin_a : (xi.z < 0.f ? kmax_a : beg); imax.z = xi.z > 0.f ? kmax_a : (xi.z < 0.f ? kmin_a : beg);
-        imin.w = xi.w > 0.f ? kmin_a : (xi.w < 0.f ? kmax_a : beg); imax.w = xi.w > 0.f ? kmax_a : (xi.w < 0.f ? kmin_a : beg);
         // ---- fold scalers + aggregators straight into the routing coefficients of each message part ----
         //   d m_k = P + Q*m_k + gmin*[k==argmin] + gmax*[k==argmax]
+        float t1 = 0.f, t2 = 0.f, tmn = 0.f, tmx = 0.f;
         float4 Pi = f4zero(), Qi = f4zero(), Pj = f4zero(), Qj = f4zero(), Pe = f4zero(), Qe = f4zero();
         float4 gmn_i = f4zero(), gmx_i = f4zero(), gmn_j = f4zero(), gmx_j = f4zero(), gmn_e = f4zero(), gmx_e = f4zero();
         if (on) {
@@ -260,6 +259,13 @@ __global__ __launch_bounds__(PNA_BLOCK, HAS_EE ? 2 : 4) void k_pna_bwd_dst(
                 const float4 hs = make_float4(var.x > 0.f ? 0.5f / sqrtf(var.x + 1e-5f) : 0.f, var.y > 0.f ? 0.5f / sqrtf(var.y + 1e-5f) : 0.f, \
                                               var.z > 0.f ? 0.5f / sqrtf(var.z + 1e-5f) : 0.f, var.w > 0.f ? 0.5f / sqrtf(var.w + 1e-5f) : 0.f); \
                 float4 p0 = f4zero(), gv = f4zero();                                                                   \
+                if (STD4) {                                                                                            \
+                    p0 = f4scale(inv_n, stage[0 * parts + (PART)][threadIdx.x]);                                       \
+                    GMN = stage[1 * parts + (PART)][threadIdx.x];                                                      \
+                    GMX = stage[2 * parts + (PART)][threadIdx.x];                                                      \
+                    const float4 vs = stage[3 * parts + (PART)][threadIdx.x];                                          \
+                    gv = make_float4(vs.x * hs.x, vs.y * hs.y, vs.z * hs.z, vs.w * hs.w);                              \
+                } else                                                                                                 \
                 for (int s = 0; s < cfg.S; ++s) {                                                                      \
                     const float f = scaler_factor(cfg.scal[s], cnt, cfg.avg_lin, cfg.avg_log);                         \
                     for (int a = 0; a < cfg.A; ++a) {                                                                  \
@@ -280,12 +286,32 @@ __global__ __launch_bounds__(PNA_BLOCK, HAS_EE ? 2 : 4) void k_pna_bwd_dst(
                 P = make_float4(p0.x - mean.x * Q.x, p0.y - mean.y * Q.y, p0.z - mean.z * Q.z, p0.w - mean.w * Q.w);   \
             }
             GSAT_FOLD(ai, 0, Pi, Qi, gmn_i, gmx_i)
+        // ---- x_i part in closed form: every in-edge carries the same vector x_i, so its gradient needs no per-edge pass.
+        //   d(att_k x_i) = Pi + Qi*att_k*x_i + gmn_i*[k == argmin] + gmx_i*[k == argmax],  arg of att*x_i = arg-min/max of att by
+        //   the sign of x_i (first slot where x_i == 0)
+        //   dx_i    = sum_k att_k * d(att_k x_i) = Pi*sum(att) + Qi*x_i*sum(att^2) + gmn_i*att[argmin] + gmx_i*att[argmax]
+        //   datt_k += <d(att_k x_i), x_i> = t1 + att_k*t2 + [k == kmin_a]*tmn + [k == kmax_a]*tmx   (per-lane partial sums)
+            {
+#define GSAT_SELF(C)                                                                                                   \
+            {                                                                                                          \
+                const float xc = xi.C;                                                                                 \
+                const float wlo = xc > 0.f ? amin : (xc < 0.f ? amax : wfirst), whi = xc > 0.f ? amax : (xc < 0.f ? amin : wfirst); \
+                dxi.C = Pi.C * sa + Qi.C * xc * sa2 + gmn_i.C * wlo + gmx_i.C * whi;                                   \
+                t1 = fmaf(Pi.C, xc, t1);                                                                               \
+                t2 = fmaf(Qi.C * xc, xc, t2);                                                                          \
+                tmn += xc > 0.f ? gmn_i.C * xc : (xc < 0.f ? gmx_i.C * xc : 0.f);                                      \
+                tmx += xc > 0.f ? gmx_i.C * xc : (xc < 0.f ? gmn_i.C * xc : 0.f);                                      \
+            }
+            float4 dxi;
+            GSAT_SELF(x) GSAT_SELF(y) GSAT_SELF(z) GSAT_SELF(w)
+#undef GSAT_SELF
+            st4(dx_self + (size_t)row * H + c, dxi);
+            }
             GSAT_FOLD(aj, 1, Pj, Qj, gmn_j, gmx_j)
             if (HAS_EE) { GSAT_FOLD(ae, 2, Pe, Qe, gmn_e, gmx_e) }
 #undef GSAT_FOLD
         }
         // ---- pass 2: per-edge gradients -------------------------------------------------------
-        float4 dxi = f4zero();
         for (int kb = beg; kb < end; kb += 4) {
             const int nb = min(4, end - kb);
             int j4[4], e4[4];
@@ -323,13 +349,7 @@ __global__ __launch_bounds__(PNA_BLOCK, HAS_EE ? 2 : 4) void k_pna_bwd_dst(
                     dm.w = fmaf(Qj.w, w * xj.w, Pj.w) + (k == jmin.w ? gmn_j.w : 0.f) + (k == jmax.w ? gmx_j.w : 0.f);
                     st4(dmsg + (size_t)k * H + c, f4scale(w, dm));
                     da += f4dot(dm, xj);
-                    float4 di;
-                    di.x = fmaf(Qi.x, w * xi.x, Pi.x) + (k == imin.x ? gmn_i.x : 0.f) + (k == imax.x ? gmx_i.x : 0.f);
-                    di.y = fmaf(Qi.y, w * xi.y, Pi.y) + (k == imin.y ? gmn_i.y : 0.f) + (k == imax.y ? gmx_i.y : 0.f);
-                    di.z = fmaf(Qi.z, w * xi.z, Pi.z) + (k == imin.z ? gmn_i.z : 0.f) + (k == imax.z ? gmx_i.z : 0.f);
-                    di.w = fmaf(Qi.w, w * xi.w, Pi.w) + (k == imin.w ? gmn_i.w : 0.f) + (k == imax.w ? gmx_i.w : 0.f);
-                    dxi = f4fma(w, di, dxi);
-                    da += f4dot(di, xi);
+                    da += t1 + w * t2 + (k == kmin_a ? tmn : 0.f) + (k == kmax_a ? tmx : 0.f);
                     if (HAS_EE) {
                         const float4 ee = ee4[u];
                         float4 de;
@@ -347,7 +367,6 @@ __global__ __launch_bounds__(PNA_BLOCK, HAS_EE ? 2 : 4) void k_pna_bwd_dst(
                 }
             }
         }
-        if (on) st4(dx_self + (size_t)row * H + c, dxi);
     }
 }
 
@@ -430,10 +449,13 @@ int gsat_pna_bwd(const float* x, const float* att, const float* edge_emb, const 
     GSAT_REQUIRE(x && dout && rowptr && dx_self, GSAT_ERR_ARG, "gsat_pna_bwd: null pointer");   /* col / eid / dmsg may be NULL when E == 0 */
     int nb, rpg;
     pna_grid(N, lpr, &nb, &rpg);
+    const bool std4 = A == 4 && S == 1 && cfg.scal[0] == 0 && cfg.aggr[0] == AGG_MEAN && cfg.aggr[1] == AGG_MIN &&
+                      cfg.aggr[2] == AGG_MAX && cfg.aggr[3] == GSAT_AGG_STD;
 #define CALL(L)                                                                                                              \
     do {                                                                                                                     \
-        if (edge_emb) k_pna_bwd_dst<L, true><<<nb, PNA_BLOCK, 0, stream>>>(x, att, edge_emb, dout, rowptr, col, eid, (int)N, (int)H, cfg, dx_self, dmsg, datt, dedge_emb, rpg); \
-        else k_pna_bwd_dst<L, false><<<nb, PNA_BLOCK, 0, stream>>>(x, att, edge_emb, dout, rowptr, col, eid, (int)N, (int)H, cfg, dx_self, dmsg, datt, dedge_emb, rpg);         \
+        if (edge_emb) k_pna_bwd_dst<L, true, false><<<nb, PNA_BLOCK, 0, stream>>>(x, att, edge_emb, dout, rowptr, col, eid, (int)N, (int)H, cfg, dx_self, dmsg, datt, dedge_emb, rpg); \
+        else if (std4) k_pna_bwd_dst<L, false, true><<<nb, PNA_BLOCK, 0, stream>>>(x, att, edge_emb, dout, rowptr, col, eid, (int)N, (int)H, cfg, dx_self, dmsg, datt, dedge_emb, rpg); \
+        else k_pna_bwd_dst<L, false, false><<<nb, PNA_BLOCK, 0, stream>>>(x, att, edge_emb, dout, rowptr, col, eid, (int)N, (int)H, cfg, dx_self, dmsg, datt, dedge_emb, rpg);         \
     } while (0)
     GSAT_LPR_DISPATCH(lpr, CALL);
 #undef CALL
