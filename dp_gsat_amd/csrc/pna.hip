@@ -88,7 +88,7 @@ __device__ __forceinline__ Acc4 self_stats(float4 xi, float sa, float sa2, float
     return r;
 }
 
-template <int LPR, bool HAS_EE>
+template <int LPR, bool HAS_EE, bool STD4>
 __global__ __launch_bounds__(PNA_BLOCK) void k_pna_fwd(
     const float* __restrict__ x, const float* __restrict__ att, const float* __restrict__ edge_emb,
     const int32_t* __restrict__ rowptr, const int32_t* __restrict__ col, const int32_t* __restrict__ eid,
@@ -140,6 +140,14 @@ __global__ __launch_bounds__(PNA_BLOCK) void k_pna_fwd(
         if (!on) continue;
         const Acc4 ai = self_stats(xi, sa, sa2, amin, amax);
         float* orow = out + (size_t)row * out_stride;
+        if (STD4) {        // (mean, min, max, std; identity), no edge part: eight fixed segments
+            float* o = orow + c;
+            st4_nt(o, agg_value4(AGG_MEAN, ai, cnt));           st4_nt(o + H, agg_value4(AGG_MEAN, aj, cnt));
+            st4_nt(o + 2 * H, agg_value4(AGG_MIN, ai, cnt));    st4_nt(o + 3 * H, agg_value4(AGG_MIN, aj, cnt));
+            st4_nt(o + 4 * H, agg_value4(AGG_MAX, ai, cnt));    st4_nt(o + 5 * H, agg_value4(AGG_MAX, aj, cnt));
+            st4_nt(o + 6 * H, agg_value4(GSAT_AGG_STD, ai, cnt)); st4_nt(o + 7 * H, agg_value4(GSAT_AGG_STD, aj, cnt));
+            continue;
+        }
         for (int s = 0; s < cfg.S; ++s) {
             const float f = scaler_factor(cfg.scal[s], cnt, cfg.avg_lin, cfg.avg_log);
             for (int a = 0; a < cfg.A; ++a) {
@@ -385,6 +393,11 @@ static inline void pna_grid(int64_t N, int lpr, int* nb, int* rpg) {
     *rpg = (int)std::max<int64_t>(1, ceil_div(N, b * gpb));
 }
 
+static inline bool is_std4(const PnaCfg& cfg) {
+    return cfg.A == 4 && cfg.S == 1 && cfg.scal[0] == 0 && cfg.aggr[0] == AGG_MEAN && cfg.aggr[1] == AGG_MIN &&
+           cfg.aggr[2] == AGG_MAX && cfg.aggr[3] == GSAT_AGG_STD;
+}
+
 static int make_cfg(const int32_t* aggr, int A, const int32_t* scal, int S, float avg_lin, float avg_log, PnaCfg* cfg) {
     GSAT_REQUIRE(aggr && scal && A >= 1 && A <= 8 && S >= 1 && S <= 8, GSAT_ERR_ARG, "pna: need 1..8 aggregators and scalers");
     cfg->A = A; cfg->S = S; cfg->avg_lin = avg_lin; cfg->avg_log = avg_log;
@@ -423,10 +436,12 @@ int gsat_pna_fwd(const float* x, const float* att, const float* edge_emb, const 
     GSAT_REQUIRE(x && rowptr && out, GSAT_ERR_ARG, "gsat_pna_fwd: null pointer");   /* col / eid may be NULL when E == 0 */
     int nb, rpg;
     pna_grid(N, lpr, &nb, &rpg);
+    const bool std4 = is_std4(cfg);
 #define CALL(L)                                                                                                              \
     do {                                                                                                                     \
-        if (edge_emb) k_pna_fwd<L, true><<<nb, PNA_BLOCK, 0, stream>>>(x, att, edge_emb, rowptr, col, eid, (int)N, (int)H, cfg, out, rpg); \
-        else k_pna_fwd<L, false><<<nb, PNA_BLOCK, 0, stream>>>(x, att, edge_emb, rowptr, col, eid, (int)N, (int)H, cfg, out, rpg);         \
+        if (edge_emb) k_pna_fwd<L, true, false><<<nb, PNA_BLOCK, 0, stream>>>(x, att, edge_emb, rowptr, col, eid, (int)N, (int)H, cfg, out, rpg); \
+        else if (std4) k_pna_fwd<L, false, true><<<nb, PNA_BLOCK, 0, stream>>>(x, att, edge_emb, rowptr, col, eid, (int)N, (int)H, cfg, out, rpg); \
+        else k_pna_fwd<L, false, false><<<nb, PNA_BLOCK, 0, stream>>>(x, att, edge_emb, rowptr, col, eid, (int)N, (int)H, cfg, out, rpg);         \
     } while (0)
     GSAT_LPR_DISPATCH(lpr, CALL);
 #undef CALL
@@ -449,8 +464,7 @@ int gsat_pna_bwd(const float* x, const float* att, const float* edge_emb, const 
     GSAT_REQUIRE(x && dout && rowptr && dx_self, GSAT_ERR_ARG, "gsat_pna_bwd: null pointer");   /* col / eid / dmsg may be NULL when E == 0 */
     int nb, rpg;
     pna_grid(N, lpr, &nb, &rpg);
-    const bool std4 = A == 4 && S == 1 && cfg.scal[0] == 0 && cfg.aggr[0] == AGG_MEAN && cfg.aggr[1] == AGG_MIN &&
-                      cfg.aggr[2] == AGG_MAX && cfg.aggr[3] == GSAT_AGG_STD;
+    const bool std4 = is_std4(cfg);
 #define CALL(L)                                                                                                              \
     do {                                                                                                                     \
         if (edge_emb) k_pna_bwd_dst<L, true, false><<<nb, PNA_BLOCK, 0, stream>>>(x, att, edge_emb, dout, rowptr, col, eid, (int)N, (int)H, cfg, dx_self, dmsg, datt, dedge_emb, rpg); \
