@@ -46,21 +46,10 @@ struct PreAct {
     }
 };
 
-// Philox seed by value, or read from device memory (`dev` != NULL): a captured hipGraph then draws a new dropout mask on
-// every replay because the host (or a graph-safe RNG op) rewrites that word between replays.
-struct SeedRef {
-    uint64_t value;
-    const uint64_t* dev;
-    __device__ __forceinline__ uint64_t get() const { return dev ? *dev : value; }
-};
-
 __device__ __forceinline__ float4 keep4(const float* mask, SeedRef sref, int layer, int row, int c, int C, float p, bool training) {
     if (!training || p <= 0.f) return make_float4(1.f, 1.f, 1.f, 1.f);
     if (mask) return ld4(mask + (size_t)row * C + c);
-    uint4 r = philox4x32(sref.get(), (uint32_t)row, (uint32_t)(c >> 2), (uint32_t)layer, 0x5A17u);
-    const float k = 1.0f / 16777216.0f;
-    return make_float4((float)(r.x >> 8) * k >= p ? 1.f : 0.f, (float)(r.y >> 8) * k >= p ? 1.f : 0.f,
-                       (float)(r.z >> 8) * k >= p ? 1.f : 0.f, (float)(r.w >> 8) * k >= p ? 1.f : 0.f);
+    return philox_keep4(sref.get(), layer, row, c, p);
 }
 
 // Sum a float4 per (slot, lane) over the 16 row slots in fixed order; result valid in slot 0.
@@ -524,6 +513,16 @@ static int check_args(const gsat_attn_args* a, const char* who) {
 using namespace gsat;
 
 extern "C" {
+
+size_t gsat_colsum_workspace_floats(int64_t C) { return (size_t)256 * (size_t)(C > 0 ? C : 0); }
+
+int gsat_colsum(const float* x, int64_t R, int64_t C, float* out, float* workspace, void* stream) {
+    GSAT_REQUIRE(R >= 0 && C >= 0 && C < (1ll << 31), GSAT_ERR_ARG, "gsat_colsum: bad extents");
+    if (C == 0) return GSAT_OK;
+    GSAT_REQUIRE(out && (x || R == 0) && workspace, GSAT_ERR_ARG, "gsat_colsum: null pointer");
+    return colsum((hipStream_t)stream, x, R, (int)C, out, workspace);
+}
+
 
 int gsat_attn_fwd(const gsat_attn_args* a, void* stream_) {
     hipStream_t stream = (hipStream_t)stream_;

@@ -107,6 +107,22 @@ __device__ __forceinline__ uint4 philox4x32(uint64_t seed, uint32_t c0, uint32_t
     }
     return make_uint4(c0, c1, c2, c3);
 }
+
+// Philox seed by value, or read from device memory (`dev` != NULL): a captured hipGraph then draws a new dropout mask on
+// every replay because the host (or a graph-safe RNG op) rewrites that word between replays.
+struct SeedRef {
+    uint64_t value;
+    const uint64_t* dev;
+    __device__ __forceinline__ uint64_t get() const { return dev ? *dev : value; }
+};
+
+// keep[row, c..c+3] in {0,1} of the dropout stream `layer` (extractor layers 1 / 2, backbone layer tails 3)
+__device__ __forceinline__ float4 philox_keep4(uint64_t seed, int layer, int row, int c, float p) {
+    uint4 r = philox4x32(seed, (uint32_t)row, (uint32_t)(c >> 2), (uint32_t)layer, 0x5A17u);
+    const float k = 1.0f / 16777216.0f;
+    return make_float4((float)(r.x >> 8) * k >= p ? 1.f : 0.f, (float)(r.y >> 8) * k >= p ? 1.f : 0.f,
+                       (float)(r.z >> 8) * k >= p ? 1.f : 0.f, (float)(r.w >> 8) * k >= p ? 1.f : 0.f);
+}
 #endif
 
 }  // namespace gsat

@@ -1,5 +1,7 @@
 // BatchNorm1d over node rows (GIN `nn.1`, PNA `batch_norms.{i}` -- src/models/gin.py:58, src/models/pna.py:45,57),
 // training and eval, with an optional fused ReLU (PNA: relu(batch_norm(conv(...)))).
+// gsat_bn_act_* add the rest of a PNA layer tail to the same passes: y = dropout(relu(BN(x)) + residual)
+// (src/models/pna.py:57-59), dropout mask from Philox (stream 3, keyed by row / column), recomputed in the backward.
 // Statistics are two-pass (mean, then variance of the centred values) with two-stage, fixed-order column sums, so
 // results are bitwise reproducible; running statistics follow torch (momentum update, unbiased running_var).
 #include "common.h"
@@ -7,6 +9,19 @@
 namespace gsat {
 
 constexpr int NB = 256, NL = 16, NS = 16;     // 16 row slots x 16 lanes (float4) = 64 channels per block
+constexpr int BN_DROPOUT_STREAM = 3;       // 1 and 2 are the extractor layers
+
+struct Tail {                 // what follows act(BN(x)): + residual, then inverted dropout
+    const float* residual;    // [N, C] or NULL
+    float p;                  // drop probability (0 = no dropout)
+    SeedRef seed;
+    __device__ __forceinline__ float4 keep_scale(int64_t row, int c) const {
+        if (p <= 0.f) return make_float4(1.f, 1.f, 1.f, 1.f);
+        const float s = 1.f / (1.f - p);
+        float4 k = philox_keep4(seed.get(), BN_DROPOUT_STREAM, (int)row, c, p);
+        return make_float4(k.x * s, k.y * s, k.z * s, k.w * s);
+    }
+};
 
 __device__ __forceinline__ float4 nslot_reduce(float4 v, float4 (*sm)[NL], int slot, int lane) {
     __syncthreads();
@@ -86,7 +101,7 @@ __global__ void k_bn_eval_stats(const float* __restrict__ running_mean, const fl
 }
 
 __global__ void k_bn_apply(const float* __restrict__ x, const float* __restrict__ mean, const float* __restrict__ rstd,
-                           const float* __restrict__ gamma, const float* __restrict__ beta, int64_t N, int C, int relu, float* __restrict__ y) {
+                           const float* __restrict__ gamma, const float* __restrict__ beta, int64_t N, int C, int relu, Tail tail, float* __restrict__ y) {
     const int C4 = C >> 2;
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < N * C4; i += (int64_t)gridDim.x * blockDim.x) {
         const int c = (int)(i % C4) * 4;
@@ -94,6 +109,8 @@ __global__ void k_bn_apply(const float* __restrict__ x, const float* __restrict_
         float4 o = make_float4(fmaf((v.x - mu.x) * rs.x, g.x, b.x), fmaf((v.y - mu.y) * rs.y, g.y, b.y),
                                fmaf((v.z - mu.z) * rs.z, g.z, b.z), fmaf((v.w - mu.w) * rs.w, g.w, b.w));
         if (relu) o = make_float4(fmaxf(o.x, 0.f), fmaxf(o.y, 0.f), fmaxf(o.z, 0.f), fmaxf(o.w, 0.f));
+        if (tail.residual) { const float4 r = ld4(tail.residual + i * 4); o = make_float4(o.x + r.x, o.y + r.y, o.z + r.z, o.w + r.w); }
+        if (tail.p > 0.f) { const float4 k = tail.keep_scale(i / C4, c); o = make_float4(o.x * k.x, o.y * k.y, o.z * k.z, o.w * k.w); }
         st4(y + i * 4, o);
     }
 }
@@ -102,7 +119,7 @@ __global__ void k_bn_apply(const float* __restrict__ x, const float* __restrict_
 __global__ __launch_bounds__(NB) void k_bn_bwd_partial(const float* __restrict__ x, const float* __restrict__ dy, const float* __restrict__ mean,
                                                        const float* __restrict__ rstd, const float* __restrict__ gamma,
                                                        const float* __restrict__ beta, int64_t N, int C, int relu, int64_t rows_per_block,
-                                                       float* __restrict__ part) {
+                                                       Tail tail, float* __restrict__ part) {
     __shared__ float4 sm[NS][NL];
     const int lane = threadIdx.x % NL, slot = threadIdx.x / NL;
     const int c = (blockIdx.x * NL + lane) * 4;
@@ -113,6 +130,7 @@ __global__ __launch_bounds__(NB) void k_bn_bwd_partial(const float* __restrict__
         const float4 mu = ld4(mean + c), rs = ld4(rstd + c), g = ld4(gamma + c), b = ld4(beta + c);
         for (int64_t r = beg + slot; r < end; r += NS) {
             float4 v = ld4(x + (size_t)r * C + c), d = ld4(dy + (size_t)r * C + c);
+            if (tail.p > 0.f) { const float4 k = tail.keep_scale(r, c); d = make_float4(d.x * k.x, d.y * k.y, d.z * k.z, d.w * k.w); }
             float4 xh = make_float4((v.x - mu.x) * rs.x, (v.y - mu.y) * rs.y, (v.z - mu.z) * rs.z, (v.w - mu.w) * rs.w);
             if (relu) {
                 d.x = fmaf(xh.x, g.x, b.x) > 0.f ? d.x : 0.f; d.y = fmaf(xh.y, g.y, b.y) > 0.f ? d.y : 0.f;
@@ -145,12 +163,14 @@ __global__ __launch_bounds__(NB) void k_bn_bwd_finalize(const float* __restrict_
 __global__ void k_bn_bwd_apply(const float* __restrict__ x, const float* __restrict__ dy, const float* __restrict__ mean,
                                const float* __restrict__ rstd, const float* __restrict__ gamma, const float* __restrict__ beta,
                                const float* __restrict__ dbeta, const float* __restrict__ dgamma, int64_t N, int C, int relu, int training,
-                               float* __restrict__ dx) {
+                               Tail tail, float* __restrict__ dx, float* __restrict__ dres) {
     const int C4 = C >> 2;
     const float inv_n = 1.f / (float)N;
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < N * C4; i += (int64_t)gridDim.x * blockDim.x) {
         const int c = (int)(i % C4) * 4;
         float4 v = ld4(x + i * 4), d = ld4(dy + i * 4), mu = ld4(mean + c), rs = ld4(rstd + c), g = ld4(gamma + c), b = ld4(beta + c);
+        if (tail.p > 0.f) { const float4 k = tail.keep_scale(i / C4, c); d = make_float4(d.x * k.x, d.y * k.y, d.z * k.z, d.w * k.w); }
+        if (dres) st4(dres + i * 4, d);                  // gradient of the residual branch: d(out)/d(residual) = dropout only
         float4 xh = make_float4((v.x - mu.x) * rs.x, (v.y - mu.y) * rs.y, (v.z - mu.z) * rs.z, (v.w - mu.w) * rs.w);
         if (relu) {
             d.x = fmaf(xh.x, g.x, b.x) > 0.f ? d.x : 0.f; d.y = fmaf(xh.y, g.y, b.y) > 0.f ? d.y : 0.f;
@@ -187,11 +207,12 @@ size_t gsat_bn_workspace_floats(int64_t N, int64_t C) {
     return (size_t)RB * (size_t)C * 2;
 }
 
-int gsat_bn_fwd(const float* x, const float* gamma, const float* beta, float* running_mean, float* running_var, int64_t N, int64_t C,
-                int training, float momentum, float eps, int relu, float* y, float* save_mean, float* save_rstd, float* workspace,
-                void* stream_) {
+int gsat_bn_act_fwd(const float* x, const float* gamma, const float* beta, float* running_mean, float* running_var, int64_t N, int64_t C,
+                    int training, float momentum, float eps, int relu, const float* residual, float dropout_p, uint64_t seed,
+                    const uint64_t* seed_dev, float* y, float* save_mean, float* save_rstd, float* workspace, void* stream_) {
     hipStream_t stream = (hipStream_t)stream_;
     GSAT_REQUIRE(N >= 0 && C > 0 && C % 4 == 0 && N < (1ll << 31), GSAT_ERR_UNSUPPORTED, "gsat_bn_fwd: C must be a positive multiple of 4");
+    GSAT_REQUIRE(dropout_p >= 0.f && dropout_p < 1.f, GSAT_ERR_ARG, "gsat_bn_act_fwd: dropout_p must be in [0, 1)");
     if (N == 0) return GSAT_OK;
     GSAT_REQUIRE(x && gamma && beta && y && save_mean && save_rstd, GSAT_ERR_ARG, "gsat_bn_fwd: null pointer");
     if (training) {
@@ -210,16 +231,26 @@ int gsat_bn_fwd(const float* x, const float* gamma, const float* beta, float* ru
         GSAT_REQUIRE(running_mean && running_var, GSAT_ERR_ARG, "gsat_bn_fwd: eval mode needs running statistics");
         k_bn_eval_stats<<<(unsigned)ceil_div(C, 256), 256, 0, stream>>>(running_mean, running_var, (int)C, eps, save_mean, save_rstd);
     }
-    k_bn_apply<<<ew_grid(N * (C / 4)), 256, 0, stream>>>(x, save_mean, save_rstd, gamma, beta, N, (int)C, relu, y);
+    const Tail tail{residual, dropout_p, SeedRef{seed, seed_dev}};
+    k_bn_apply<<<ew_grid(N * (C / 4)), 256, 0, stream>>>(x, save_mean, save_rstd, gamma, beta, N, (int)C, relu, tail, y);
     GSAT_LAUNCH_CHECK();
     return GSAT_OK;
 }
 
-int gsat_bn_bwd(const float* x, const float* dy, const float* gamma, const float* beta, const float* save_mean, const float* save_rstd,
-                int64_t N, int64_t C, int training, int relu, float* dx, float* dgamma, float* dbeta, float* workspace, void* stream_) {
+int gsat_bn_fwd(const float* x, const float* gamma, const float* beta, float* running_mean, float* running_var, int64_t N, int64_t C,
+                int training, float momentum, float eps, int relu, float* y, float* save_mean, float* save_rstd, float* workspace,
+                void* stream_) {
+    return gsat_bn_act_fwd(x, gamma, beta, running_mean, running_var, N, C, training, momentum, eps, relu, nullptr, 0.f, 0, nullptr, y,
+                           save_mean, save_rstd, workspace, stream_);
+}
+
+int gsat_bn_act_bwd(const float* x, const float* dy, const float* gamma, const float* beta, const float* save_mean, const float* save_rstd,
+                    int64_t N, int64_t C, int training, int relu, float dropout_p, uint64_t seed, const uint64_t* seed_dev, float* dx,
+                    float* dresidual, float* dgamma, float* dbeta, float* workspace, void* stream_) {
     hipStream_t stream = (hipStream_t)stream_;
     GSAT_REQUIRE(N >= 0 && C > 0 && C % 4 == 0 && N < (1ll << 31), GSAT_ERR_UNSUPPORTED, "gsat_bn_bwd: C must be a positive multiple of 4");
     GSAT_REQUIRE(dgamma && dbeta, GSAT_ERR_ARG, "gsat_bn_bwd: null gradient output");
+    GSAT_REQUIRE(dropout_p >= 0.f && dropout_p < 1.f, GSAT_ERR_ARG, "gsat_bn_act_bwd: dropout_p must be in [0, 1)");
     if (N == 0) {
         GSAT_CHECK_HIP(hipMemsetAsync(dgamma, 0, sizeof(float) * C, stream));
         GSAT_CHECK_HIP(hipMemsetAsync(dbeta, 0, sizeof(float) * C, stream));
@@ -228,11 +259,18 @@ int gsat_bn_bwd(const float* x, const float* dy, const float* gamma, const float
     GSAT_REQUIRE(x && dy && gamma && beta && save_mean && save_rstd && dx && workspace, GSAT_ERR_ARG, "gsat_bn_bwd: null pointer");
     int64_t RB, rpb;
     row_blocks(N, &RB, &rpb);
-    k_bn_bwd_partial<<<dim3((unsigned)ceil_div(C, 64), (unsigned)RB), NB, 0, stream>>>(x, dy, save_mean, save_rstd, gamma, beta, N, (int)C, relu, rpb, workspace);
+    const Tail tail{nullptr, dropout_p, SeedRef{seed, seed_dev}};
+    k_bn_bwd_partial<<<dim3((unsigned)ceil_div(C, 64), (unsigned)RB), NB, 0, stream>>>(x, dy, save_mean, save_rstd, gamma, beta, N, (int)C, relu, rpb, tail, workspace);
     k_bn_bwd_finalize<<<(unsigned)ceil_div(C, 64), NB, 0, stream>>>(workspace, (int)RB, (int)C, dbeta, dgamma);
-    k_bn_bwd_apply<<<ew_grid(N * (C / 4)), 256, 0, stream>>>(x, dy, save_mean, save_rstd, gamma, beta, dbeta, dgamma, N, (int)C, relu, training, dx);
+    k_bn_bwd_apply<<<ew_grid(N * (C / 4)), 256, 0, stream>>>(x, dy, save_mean, save_rstd, gamma, beta, dbeta, dgamma, N, (int)C, relu, training, tail, dx, dresidual);
     GSAT_LAUNCH_CHECK();
     return GSAT_OK;
+}
+
+int gsat_bn_bwd(const float* x, const float* dy, const float* gamma, const float* beta, const float* save_mean, const float* save_rstd,
+                int64_t N, int64_t C, int training, int relu, float* dx, float* dgamma, float* dbeta, float* workspace, void* stream_) {
+    return gsat_bn_act_bwd(x, dy, gamma, beta, save_mean, save_rstd, N, C, training, relu, 0.f, 0, nullptr, dx, nullptr, dgamma, dbeta,
+                           workspace, stream_);
 }
 
 }  // extern "C"

@@ -59,17 +59,31 @@ class BatchNorm1d(nn.BatchNorm1d):
     with 2-D fp32 input; anything else (CPU tensors in the host-protocol tests, odd shapes) uses torch's implementation.
     ``fused_relu`` applies ReLU inside the kernel (PNA)."""
 
-    def forward(self, x, fused_relu: bool = False):
+    def forward(self, x, fused_relu: bool = False, residual=None, dropout_p: float = 0.0):
+        """``residual`` / ``dropout_p``: y = dropout_p(act(BN(x)) + residual) in the same kernels (the PNA layer tail)."""
         hip_ok = (x.is_cuda and x.dim() == 2 and x.dtype == torch.float32 and self.affine and x.shape[1] % 4 == 0
                   and (self.training or self.track_running_stats) and self.momentum is not None and x.shape[0] > 0)
+        p = float(dropout_p) if self.training else 0.0
         if not hip_ok:
             y = super().forward(x)
-            return torch.relu(y) if fused_relu else y
+            y = torch.relu(y) if fused_relu else y
+            if residual is not None:
+                y = y + residual
+            return torch.nn.functional.dropout(y, p, training=True) if p > 0.0 else y
         training = self.training or not self.track_running_stats
         if self.training and self.track_running_stats and self.num_batches_tracked is not None:
             self.num_batches_tracked.add_(1)
+        seed, seed_dev = 0, None
+        if p > 0.0:
+            from .graph_index import sync_free
+            from .ops import new_seed
+            if sync_free():        # no host round trip inside a captured step: the seed word lives on the device
+                seed_dev = torch.empty(1, dtype=torch.int64, device=x.device).random_()
+            else:
+                seed = new_seed()
         return BatchNormFn.apply(x, self.weight, self.bias, self.running_mean if self.track_running_stats else None,
-                                 self.running_var if self.track_running_stats else None, training, self.momentum, self.eps, fused_relu)
+                                 self.running_var if self.track_running_stats else None, training, self.momentum, self.eps, fused_relu,
+                                 residual, p, seed, seed_dev)
 
 
 class BatchNorm(nn.Module):
@@ -79,8 +93,8 @@ class BatchNorm(nn.Module):
         super().__init__()
         self.module = BatchNorm1d(in_channels)
 
-    def forward(self, x, fused_relu: bool = False):
-        return self.module(x, fused_relu)
+    def forward(self, x, fused_relu: bool = False, residual=None, dropout_p: float = 0.0):
+        return self.module(x, fused_relu, residual, dropout_p)
 
 
 def _segments(batch, edge_index=None, num_nodes=None):

@@ -446,36 +446,56 @@ class EmbeddingSum(torch.autograd.Function):
 
 
 class BatchNormFn(torch.autograd.Function):
-    """BatchNorm1d over rows with optional fused ReLU (src/models/gin.py:58, src/models/pna.py:57)."""
+    """BatchNorm1d over rows with optional fused ReLU (src/models/gin.py:58, src/models/pna.py:45,57) and, for PNA, the rest of
+    the layer tail in the same passes: y = dropout_p(relu(BN(x)) + residual)  (src/models/pna.py:57-59).  The dropout mask is
+    Philox stream 3 keyed by (seed, row, column); ``seed_dev`` (a 1-element int64 device tensor) replaces the host seed in
+    sync-free / hipGraph mode."""
 
     @staticmethod
-    def forward(ctx, x, weight, bias, running_mean, running_var, training, momentum, eps, relu):
+    def forward(ctx, x, weight, bias, running_mean, running_var, training, momentum, eps, relu, residual=None, dropout_p=0.0,
+                seed=0, seed_dev=None):
         from ._lib import load
-        x, weight, bias = _f32c(x), _f32c(weight), _f32c(bias)
+        x, weight, bias, residual = _f32c(x), _f32c(weight), _f32c(bias), _f32c(residual)
         N, C = x.shape
+        if residual is not None and residual.shape != x.shape:
+            raise ValueError("residual must have the shape of the normalised tensor")
         y = torch.empty_like(x)
         mean = torch.empty(C, dtype=torch.float32, device=x.device)
         rstd = torch.empty(C, dtype=torch.float32, device=x.device)
         ws = torch.empty(max(int(load().gsat_bn_workspace_floats(N, C)), 1), dtype=torch.float32, device=x.device)
-        call("gsat_bn_fwd", ptr(x), ptr(weight), ptr(bias), ptr(running_mean), ptr(running_var), N, C, int(training),
-             float(momentum), float(eps), int(relu), ptr(y), ptr(mean), ptr(rstd), ptr(ws), stream())
+        call("gsat_bn_act_fwd", ptr(x), ptr(weight), ptr(bias), ptr(running_mean), ptr(running_var), N, C, int(training),
+             float(momentum), float(eps), int(relu), ptr(residual), float(dropout_p), int(seed), ptr(seed_dev), ptr(y), ptr(mean),
+             ptr(rstd), ptr(ws), stream())
         ctx.save_for_backward(x, weight, bias, mean, rstd)
-        ctx.flags = (bool(training), bool(relu))
+        ctx.flags = (bool(training), bool(relu), float(dropout_p), int(seed), residual is not None)
+        ctx.seed_dev = seed_dev
         return y
 
     @staticmethod
     def backward(ctx, dy):
         from ._lib import load
         x, weight, bias, mean, rstd = ctx.saved_tensors
-        training, relu = ctx.flags
+        training, relu, dropout_p, seed, has_res = ctx.flags
         dy = _f32c(dy)
         N, C = x.shape
         dx = torch.empty_like(x)
+        dres = torch.empty_like(x) if has_res and ctx.needs_input_grad[9] else None
         dgamma, dbeta = torch.empty_like(weight), torch.empty_like(bias)
         ws = torch.empty(max(int(load().gsat_bn_workspace_floats(N, C)), 1), dtype=torch.float32, device=x.device)
-        call("gsat_bn_bwd", ptr(x), ptr(dy), ptr(weight), ptr(bias), ptr(mean), ptr(rstd), N, C, int(training), int(relu),
-             ptr(dx), ptr(dgamma), ptr(dbeta), ptr(ws), stream())
-        return dx, dgamma, dbeta, None, None, None, None, None, None
+        call("gsat_bn_act_bwd", ptr(x), ptr(dy), ptr(weight), ptr(bias), ptr(mean), ptr(rstd), N, C, int(training), int(relu),
+             dropout_p, seed, ptr(ctx.seed_dev), ptr(dx), ptr(dres), ptr(dgamma), ptr(dbeta), ptr(ws), stream())
+        return dx, dgamma, dbeta, None, None, None, None, None, None, dres, None, None, None
+
+
+def colsum(x):
+    """Deterministic column sum of a 2-D fp32 device tensor (bias gradients)."""
+    from ._lib import load
+    x = _f32c(x)
+    R, C = x.shape
+    out = torch.empty(C, dtype=torch.float32, device=x.device)
+    ws = torch.empty(max(int(load().gsat_colsum_workspace_floats(C)), 1), dtype=torch.float32, device=x.device)
+    call("gsat_colsum", ptr(x), R, C, ptr(out), ptr(ws), stream())
+    return out
 
 
 def _gemm(a_t, b_t, M, N, K, A, lda, B, ldb, C, ldc, bias=None, split=True):
@@ -526,7 +546,7 @@ class LinearFn(torch.autograd.Function):
         if ctx.needs_input_grad[1]:
             dw = torch.empty_like(weight)
             _gemm(1, 0, n_out, n_in, rows, dy, n_out, x, n_in, dw, n_in, split=big)
-        db = dy.sum(0) if ctx.has_bias and ctx.needs_input_grad[2] else None
+        db = colsum(dy) if ctx.has_bias and ctx.needs_input_grad[2] else None
         return dx, dw, db
 
 

@@ -52,9 +52,9 @@ class PNA(nn.Module):
         if edge_attr is not None:
             edge_attr = self.edge_encoder(edge_attr)
         for conv, batch_norm in zip(self.convs, self.batch_norms):
-            h = batch_norm(conv(x, edge_index, edge_attr, edge_atten=edge_atten, index=index), fused_relu=True)   # relu(BN(.))
-            x = h + x
-            x = F.dropout(x, self.dropout_p, training=self.training)
+            # h = relu(BN(conv)); x = h + x; x = dropout(x)  (src/models/pna.py:57-59) -- one fused pass after the statistics
+            x = batch_norm(conv(x, edge_index, edge_attr, edge_atten=edge_atten, index=index), fused_relu=True, residual=x,
+                           dropout_p=self.dropout_p)
         return x
 
     def forward(self, x, edge_index, batch, edge_attr, edge_atten=None):

@@ -193,6 +193,30 @@ int gsat_bn_bwd(const float* x, const float* dy, const float* gamma, const float
                 const float* save_rstd, int64_t N, int64_t C, int training, int relu, float* dx, float* dgamma,
                 float* dbeta, float* workspace, void* stream);
 
+/*
+ * The tail of a PNA layer in the same passes:  y = dropout_p( [relu](BN(x)) + residual )
+ * replaces: `h = F.relu(batch_norm(conv(...))); x = h + x; x = F.dropout(x, p, training)` (src/models/pna.py:57-59).
+ * residual may be NULL; dropout_p = 0 disables dropout (eval).  The keep mask is Philox stream 3, i.e.
+ * gsat_philox_keep_mask(seed, 3, N, C, p) -- by value, or read from *seed_dev when that is not NULL (hipGraph replays) --
+ * and is recomputed in the backward, which also returns dresidual = dy * keep / (1 - p) (NULL to skip).
+ */
+int gsat_bn_act_fwd(const float* x, const float* gamma, const float* beta, float* running_mean, float* running_var,
+                    int64_t N, int64_t C, int training, float momentum, float eps, int relu, const float* residual,
+                    float dropout_p, uint64_t seed, const uint64_t* seed_dev, float* y, float* save_mean,
+                    float* save_rstd, float* workspace, void* stream);
+int gsat_bn_act_bwd(const float* x, const float* dy, const float* gamma, const float* beta, const float* save_mean,
+                    const float* save_rstd, int64_t N, int64_t C, int training, int relu, float dropout_p,
+                    uint64_t seed, const uint64_t* seed_dev, float* dx, float* dresidual, float* dgamma,
+                    float* dbeta, float* workspace, void* stream);
+
+/*
+ * out[c] = sum_r x[r,c], two-stage fixed-order reduction (bitwise reproducible).  Bias gradients of the Linear layers
+ * (replaces the autograd `sum(0)` of nn.Linear in src/models/gin.py:55-62, src/models/conv_layers.py:153-155).
+ * workspace: gsat_colsum_workspace_floats(C) floats.
+ */
+size_t gsat_colsum_workspace_floats(int64_t C);
+int gsat_colsum(const float* x, int64_t R, int64_t C, float* out, float* workspace, void* stream);
+
 /* =============================== categorical encoders (ogb) ================================= */
 
 /*

@@ -1,6 +1,7 @@
 """Profile driver: the whole GSAT training step on one workload (run under rocprofv3)."""
 import sys, torch
-sys.path.insert(0, ".")
+import os
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from bench import WORKLOADS, FullStep, local_shard, timed
 name = sys.argv[1] if len(sys.argv) > 1 else "c3"
 wl = dict(WORKLOADS[name], key=name)

@@ -1,6 +1,7 @@
 """Micro-benchmark of gsat_gemm_f32 at the extractor's shapes (HIP events around back-to-back launches)."""
 import sys, torch
-sys.path.insert(0, ".")
+import os
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from dp_gsat_amd._lib import call, load, ptr, stream
 dev = torch.device("cuda:0")
 shapes = [  # (a_t, b_t, M, N, K, label)
