@@ -152,11 +152,11 @@ __global__ __launch_bounds__(GT) void k_gemm_f32(const float* __restrict__ A, in
                     float* dst = Cb + (size_t)row * ldc + col;
                     v = make_float4(v.x + bv.x, v.y + bv.y, v.z + bv.z, v.w + bv.w);
                     if (col + 3 < N) {
-                        if (accumulate) { float4 o = ld4(dst); v = make_float4(v.x + o.x, v.y + o.y, v.z + o.z, v.w + o.w); }
-                        st4(dst, v);
+                        if (accumulate & 1) { float4 o = ld4(dst); v = make_float4(v.x + o.x, v.y + o.y, v.z + o.z, v.w + o.w); }
+                        if (accumulate & 2) st4_nt(dst, v); else st4(dst, v);      // bit 1: streaming output (not re-read soon)
                     } else {                                 // ragged right edge (N % 4 != 0 only for k-contiguous B)
                         const float e[4] = {v.x, v.y, v.z, v.w};
-                        for (int q = 0; q < 4 && col + q < N; ++q) dst[q] = accumulate ? dst[q] + e[q] : e[q];
+                        for (int q = 0; q < 4 && col + q < N; ++q) dst[q] = (accumulate & 1) ? dst[q] + e[q] : e[q];
                     }
                 }
             }
@@ -330,11 +330,11 @@ __global__ __launch_bounds__(GT) void k_gemm_bf16x3(const float* __restrict__ A,
                     float* dst = Cb + (size_t)row * ldc + col;
                     v = make_float4(v.x + bv.x, v.y + bv.y, v.z + bv.z, v.w + bv.w);
                     if (col + 3 < N) {
-                        if (accumulate) { float4 o = ld4(dst); v = make_float4(v.x + o.x, v.y + o.y, v.z + o.z, v.w + o.w); }
-                        st4(dst, v);
+                        if (accumulate & 1) { float4 o = ld4(dst); v = make_float4(v.x + o.x, v.y + o.y, v.z + o.z, v.w + o.w); }
+                        if (accumulate & 2) st4_nt(dst, v); else st4(dst, v);      // bit 1: streaming output (not re-read soon)
                     } else {
                         const float e[4] = {v.x, v.y, v.z, v.w};
-                        for (int q = 0; q < 4 && col + q < N; ++q) dst[q] = accumulate ? dst[q] + e[q] : e[q];
+                        for (int q = 0; q < 4 && col + q < N; ++q) dst[q] = (accumulate & 1) ? dst[q] + e[q] : e[q];
                     }
                 }
             }
@@ -415,7 +415,9 @@ int gemm_f32(hipStream_t stream, bool a_t, bool b_t, int64_t M, int64_t N, int64
     float* out = C;
     int64_t ldo = ldc;
     size_t slab = 0;
-    int acc_flag = accumulate ? 1 : 0;
+    // outputs too large for the L2s / Infinity Cache to keep until their consumer runs are written with non-temporal stores
+    static const int nt_mode = getenv("GSAT_GEMM_NT") ? atoi(getenv("GSAT_GEMM_NT")) : 1;
+    int acc_flag = (accumulate ? 1 : 0) | ((nt_mode && !accumulate && (size_t)M * N * 4 >= ((size_t)64 << 20)) ? 2 : 0);
     const float* bptr = bias;
     if (splits > 1) {
         GSAT_REQUIRE(ws && ws_floats >= (size_t)splits * M * N, GSAT_ERR_WORKSPACE, "gemm_f32: split-K workspace too small");

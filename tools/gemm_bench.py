@@ -7,7 +7,7 @@ dev = torch.device("cuda:0")
 shapes = [  # (a_t, b_t, M, N, K, label)
     (0, 1, 51639, 256, 128, "C3 P=emb W1^T"), (0, 1, 51639, 128, 256, "C3 h2=a1 W2^T"), (0, 0, 51639, 256, 128, "C3 da1=dh2 W2"),
     (0, 0, 51639, 128, 256, "C3 demb=dh1 W1"), (1, 0, 128, 256, 51639, "C3 dW2 (split-K)"), (1, 0, 256, 128, 51639, "C3 dW1 (split-K)"),
-    (0, 1, 51639, 128, 1024, "C3 post_nn fwd"), (1, 0, 128, 1024, 51639, "C3 post_nn dW"),
+    (0, 1, 51639, 128, 1024, "C3 post_nn fwd"), (0, 0, 51639, 1024, 128, "C3 post_nn dx"), (1, 0, 128, 1024, 51639, "C3 post_nn dW"),
     (0, 1, 377532, 256, 1024, "c5s h2"), (0, 0, 377532, 1024, 256, "c5s da1"), (1, 0, 256, 1024, 377532, "c5s dW2"),
 ]
 for a_t, b_t, M, N, K, label in shapes:
