@@ -88,7 +88,7 @@ __device__ __forceinline__ Acc4 self_stats(float4 xi, float sa, float sa2, float
     return r;
 }
 
-template <int LPR, bool HAS_EE, bool STD4>
+template <int LPR, bool HAS_EE, int NAGG>
 __global__ __launch_bounds__(PNA_BLOCK) void k_pna_fwd(
     const float* __restrict__ x, const float* __restrict__ att, const float* __restrict__ edge_emb,
     const int32_t* __restrict__ rowptr, const int32_t* __restrict__ col, const int32_t* __restrict__ eid,
@@ -140,12 +140,13 @@ __global__ __launch_bounds__(PNA_BLOCK) void k_pna_fwd(
         if (!on) continue;
         const Acc4 ai = self_stats(xi, sa, sa2, amin, amax);
         float* orow = out + (size_t)row * out_stride;
-        if (STD4) {        // (mean, min, max, std; identity), no edge part: eight fixed segments
+        if (NAGG) {        // (mean, min, max, std[, sum]; identity), no edge part: 2 * NAGG fixed segments
             float* o = orow + c;
             st4_nt(o, agg_value4(AGG_MEAN, ai, cnt));           st4_nt(o + H, agg_value4(AGG_MEAN, aj, cnt));
             st4_nt(o + 2 * H, agg_value4(AGG_MIN, ai, cnt));    st4_nt(o + 3 * H, agg_value4(AGG_MIN, aj, cnt));
             st4_nt(o + 4 * H, agg_value4(AGG_MAX, ai, cnt));    st4_nt(o + 5 * H, agg_value4(AGG_MAX, aj, cnt));
             st4_nt(o + 6 * H, agg_value4(GSAT_AGG_STD, ai, cnt)); st4_nt(o + 7 * H, agg_value4(GSAT_AGG_STD, aj, cnt));
+            if (NAGG == 5) { st4_nt(o + 8 * H, ai.s); st4_nt(o + 9 * H, aj.s); }
             continue;
         }
         for (int s = 0; s < cfg.S; ++s) {
@@ -160,9 +161,9 @@ __global__ __launch_bounds__(PNA_BLOCK) void k_pna_fwd(
     }
 }
 
-// STD4: the configuration of every PNA YAML of the reference (aggregators mean,min,max,std; scaler identity) with the
+// NAGG = 4 | 5: the configurations of the reference's PNA YAMLs (aggregators mean,min,max,std[,sum]; scaler identity) with the
 // segment loop resolved at compile time; the generic instantiation covers every other aggregator / scaler list.
-template <int LPR, bool HAS_EE, bool STD4>
+template <int LPR, bool HAS_EE, int NAGG>
 __global__ __launch_bounds__(PNA_BLOCK, HAS_EE ? 2 : 4) void k_pna_bwd_dst(
     const float* __restrict__ x, const float* __restrict__ att, const float* __restrict__ edge_emb,
     const float* __restrict__ dout, const int32_t* __restrict__ rowptr, const int32_t* __restrict__ col,
@@ -171,7 +172,7 @@ __global__ __launch_bounds__(PNA_BLOCK, HAS_EE ? 2 : 4) void k_pna_bwd_dst(
     constexpr int GPB = PNA_BLOCK / LPR;
     // The upstream gradient row (S*A*parts segments of H floats, 64 % of the kernel's bytes) is fetched by LDS-DMA at
     // the top of the row, so its HBM latency overlaps the index -> att -> x_j dependency chain without holding VGPRs.
-    constexpr int MAXSEG = 8;
+    constexpr int MAXSEG = NAGG == 5 ? 10 : 8;
     __shared__ float4 stage[MAXSEG][PNA_BLOCK];
     const int lane = threadIdx.x % LPR;
     const int c = lane * 4;
@@ -180,7 +181,7 @@ __global__ __launch_bounds__(PNA_BLOCK, HAS_EE ? 2 : 4) void k_pna_bwd_dst(
     const int F = parts * H;
     const size_t out_stride = (size_t)cfg.S * cfg.A * F;
     const int nseg = cfg.S * cfg.A * parts;
-    const bool staged = STD4 || nseg <= MAXSEG;
+    const bool staged = NAGG != 0 || nseg <= MAXSEG;
     const int wave_base = (threadIdx.x >> 6) << 6;
     const int grp = pna_xcd_remap(blockIdx.x, gridDim.x) * GPB + threadIdx.x / LPR;
     int row = grp * rows_per_group;
@@ -267,8 +268,10 @@ __global__ __launch_bounds__(PNA_BLOCK, HAS_EE ? 2 : 4) void k_pna_bwd_dst(
                 const float4 hs = make_float4(var.x > 0.f ? 0.5f / sqrtf(var.x + 1e-5f) : 0.f, var.y > 0.f ? 0.5f / sqrtf(var.y + 1e-5f) : 0.f, \
                                               var.z > 0.f ? 0.5f / sqrtf(var.z + 1e-5f) : 0.f, var.w > 0.f ? 0.5f / sqrtf(var.w + 1e-5f) : 0.f); \
                 float4 p0 = f4zero(), gv = f4zero();                                                                   \
-                if (STD4) {                                                                                            \
+                if (NAGG) {                                                                                            \
                     p0 = f4scale(inv_n, stage[0 * parts + (PART)][threadIdx.x]);                                       \
+                    if (NAGG == 5) { const float4 vsum = stage[4 * parts + (PART)][threadIdx.x];                       \
+                                     p0 = make_float4(p0.x + vsum.x, p0.y + vsum.y, p0.z + vsum.z, p0.w + vsum.w); }   \
                     GMN = stage[1 * parts + (PART)][threadIdx.x];                                                      \
                     GMX = stage[2 * parts + (PART)][threadIdx.x];                                                      \
                     const float4 vs = stage[3 * parts + (PART)][threadIdx.x];                                          \
@@ -393,9 +396,12 @@ static inline void pna_grid(int64_t N, int lpr, int* nb, int* rpg) {
     *rpg = (int)std::max<int64_t>(1, ceil_div(N, b * gpb));
 }
 
-static inline bool is_std4(const PnaCfg& cfg) {
-    return cfg.A == 4 && cfg.S == 1 && cfg.scal[0] == 0 && cfg.aggr[0] == AGG_MEAN && cfg.aggr[1] == AGG_MIN &&
-           cfg.aggr[2] == AGG_MAX && cfg.aggr[3] == GSAT_AGG_STD;
+// 4 / 5 for the aggregator lists (mean,min,max,std) / (mean,min,max,std,sum) with the identity scaler, else 0
+static inline int fixed_aggregators(const PnaCfg& cfg) {
+    if (cfg.S != 1 || cfg.scal[0] != 0 || (cfg.A != 4 && cfg.A != 5)) return 0;
+    if (cfg.aggr[0] != AGG_MEAN || cfg.aggr[1] != AGG_MIN || cfg.aggr[2] != AGG_MAX || cfg.aggr[3] != GSAT_AGG_STD) return 0;
+    if (cfg.A == 5 && cfg.aggr[4] != AGG_SUM) return 0;
+    return cfg.A;
 }
 
 static int make_cfg(const int32_t* aggr, int A, const int32_t* scal, int S, float avg_lin, float avg_log, PnaCfg* cfg) {
@@ -436,12 +442,13 @@ int gsat_pna_fwd(const float* x, const float* att, const float* edge_emb, const 
     GSAT_REQUIRE(x && rowptr && out, GSAT_ERR_ARG, "gsat_pna_fwd: null pointer");   /* col / eid may be NULL when E == 0 */
     int nb, rpg;
     pna_grid(N, lpr, &nb, &rpg);
-    const bool std4 = is_std4(cfg);
+    const int nagg = fixed_aggregators(cfg);
 #define CALL(L)                                                                                                              \
     do {                                                                                                                     \
-        if (edge_emb) k_pna_fwd<L, true, false><<<nb, PNA_BLOCK, 0, stream>>>(x, att, edge_emb, rowptr, col, eid, (int)N, (int)H, cfg, out, rpg); \
-        else if (std4) k_pna_fwd<L, false, true><<<nb, PNA_BLOCK, 0, stream>>>(x, att, edge_emb, rowptr, col, eid, (int)N, (int)H, cfg, out, rpg); \
-        else k_pna_fwd<L, false, false><<<nb, PNA_BLOCK, 0, stream>>>(x, att, edge_emb, rowptr, col, eid, (int)N, (int)H, cfg, out, rpg);         \
+        if (edge_emb) k_pna_fwd<L, true, 0><<<nb, PNA_BLOCK, 0, stream>>>(x, att, edge_emb, rowptr, col, eid, (int)N, (int)H, cfg, out, rpg); \
+        else if (nagg == 4) k_pna_fwd<L, false, 4><<<nb, PNA_BLOCK, 0, stream>>>(x, att, edge_emb, rowptr, col, eid, (int)N, (int)H, cfg, out, rpg); \
+        else if (nagg == 5) k_pna_fwd<L, false, 5><<<nb, PNA_BLOCK, 0, stream>>>(x, att, edge_emb, rowptr, col, eid, (int)N, (int)H, cfg, out, rpg); \
+        else k_pna_fwd<L, false, 0><<<nb, PNA_BLOCK, 0, stream>>>(x, att, edge_emb, rowptr, col, eid, (int)N, (int)H, cfg, out, rpg);         \
     } while (0)
     GSAT_LPR_DISPATCH(lpr, CALL);
 #undef CALL
@@ -464,12 +471,13 @@ int gsat_pna_bwd(const float* x, const float* att, const float* edge_emb, const 
     GSAT_REQUIRE(x && dout && rowptr && dx_self, GSAT_ERR_ARG, "gsat_pna_bwd: null pointer");   /* col / eid / dmsg may be NULL when E == 0 */
     int nb, rpg;
     pna_grid(N, lpr, &nb, &rpg);
-    const bool std4 = is_std4(cfg);
+    const int nagg = fixed_aggregators(cfg);
 #define CALL(L)                                                                                                              \
     do {                                                                                                                     \
-        if (edge_emb) k_pna_bwd_dst<L, true, false><<<nb, PNA_BLOCK, 0, stream>>>(x, att, edge_emb, dout, rowptr, col, eid, (int)N, (int)H, cfg, dx_self, dmsg, datt, dedge_emb, rpg); \
-        else if (std4) k_pna_bwd_dst<L, false, true><<<nb, PNA_BLOCK, 0, stream>>>(x, att, edge_emb, dout, rowptr, col, eid, (int)N, (int)H, cfg, dx_self, dmsg, datt, dedge_emb, rpg); \
-        else k_pna_bwd_dst<L, false, false><<<nb, PNA_BLOCK, 0, stream>>>(x, att, edge_emb, dout, rowptr, col, eid, (int)N, (int)H, cfg, dx_self, dmsg, datt, dedge_emb, rpg);         \
+        if (edge_emb) k_pna_bwd_dst<L, true, 0><<<nb, PNA_BLOCK, 0, stream>>>(x, att, edge_emb, dout, rowptr, col, eid, (int)N, (int)H, cfg, dx_self, dmsg, datt, dedge_emb, rpg); \
+        else if (nagg == 4) k_pna_bwd_dst<L, false, 4><<<nb, PNA_BLOCK, 0, stream>>>(x, att, edge_emb, dout, rowptr, col, eid, (int)N, (int)H, cfg, dx_self, dmsg, datt, dedge_emb, rpg); \
+        else if (nagg == 5) k_pna_bwd_dst<L, false, 5><<<nb, PNA_BLOCK, 0, stream>>>(x, att, edge_emb, dout, rowptr, col, eid, (int)N, (int)H, cfg, dx_self, dmsg, datt, dedge_emb, rpg); \
+        else k_pna_bwd_dst<L, false, 0><<<nb, PNA_BLOCK, 0, stream>>>(x, att, edge_emb, dout, rowptr, col, eid, (int)N, (int)H, cfg, dx_self, dmsg, datt, dedge_emb, rpg);         \
     } while (0)
     GSAT_LPR_DISPATCH(lpr, CALL);
 #undef CALL
