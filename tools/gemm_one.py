@@ -1,0 +1,15 @@
+"""Runs ONE split-bf16 GEMM shape repeatedly (for rocprofv3 --pmc passes).  usage: gemm_one.py a_t b_t M N K [reps]"""
+import os, sys, torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from dp_gsat_amd._lib import call, load, ptr, stream
+a_t, b_t, M, N, K = [int(v) for v in sys.argv[1:6]]
+reps = int(sys.argv[6]) if len(sys.argv) > 6 else 30
+dev = torch.device("cuda:0")
+A = torch.randn((K, M) if a_t else (M, K), device=dev)
+B = torch.randn((N, K) if b_t else (K, N), device=dev)
+C = torch.empty(M, N, device=dev)
+wsf = int(load().gsat_gemm_workspace_floats(a_t, M, N, K))
+ws = torch.empty(max(wsf, 1), device=dev)
+for _ in range(reps):
+    call("gsat_gemm_bf16x3", a_t, b_t, M, N, K, ptr(A), A.shape[1], ptr(B), B.shape[1], ptr(C), N, None, 0, ptr(ws), wsf, stream())
+torch.cuda.synchronize()
