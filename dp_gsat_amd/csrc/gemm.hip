@@ -435,8 +435,12 @@ int gemm_f32(hipStream_t stream, bool a_t, bool b_t, int64_t M, int64_t N, int64
     GSAT_REQUIRE(((uintptr_t)A % 16 == 0) && ((uintptr_t)B % 16 == 0) && ((uintptr_t)C % 16 == 0) && ldc % 4 == 0 && (!bias || (uintptr_t)bias % 16 == 0),
                  GSAT_ERR_ARG, "gemm_f32: operands, output and bias must be 16-byte aligned with ldc % 4 == 0");
     const int splits = gemm_splits(M, N, K, a_t);
+    const bool split = use_bf16x3(M, N, K, allow_split);
     int tm = 2, tn = 2;
     if (splits == 1) gemm_tile(M, N, K, &tm, &tn);
+    // split-bf16: the per-tile staging (fp32 -> hi/lo, LDS planes) is what costs, so the largest tile wins even when it leaves
+    // fewer workgroups than CUs x occupancy (51 639 x 128 x 1024: 57 us at 128x128 against 69 us at 128x64)
+    if (split && splits == 1 && !getenv("GSAT_GEMM_TILE")) { tm = 2; tn = N > 64 ? 2 : 1; }
     dim3 grid((unsigned)ceil_div(N, 64 * tn), (unsigned)ceil_div(M, 64 * tm), (unsigned)splits);
     int kps = (int)(ceil_div(ceil_div(K, splits), GK) * GK);
     float* out = C;
@@ -451,12 +455,13 @@ int gemm_f32(hipStream_t stream, bool a_t, bool b_t, int64_t M, int64_t N, int64
         GSAT_REQUIRE(!bias, GSAT_ERR_UNSUPPORTED, "gemm_f32: bias with split-K");
         out = ws; ldo = N; slab = (size_t)M * N; acc_flag = 0;
     }
-    const bool split = use_bf16x3(M, N, K, allow_split);
 #define LAUNCH(AT, BT)                                                                                                              \
     do {                                                                                                                            \
         if (split) {                                                                                                                \
-            if (tn == 2) k_gemm_bf16x3<AT, BT, 2, 2><<<dim3((unsigned)ceil_div(N, 128), (unsigned)ceil_div(M, 128), (unsigned)splits), GT, 0, stream>>>(A, lda, B, ldb, out, ldo, (int)M, (int)N, (int)K, kps, bptr, acc_flag, slab); \
-            else k_gemm_bf16x3<AT, BT, 2, 1><<<dim3((unsigned)ceil_div(N, 64), (unsigned)ceil_div(M, 128), (unsigned)splits), GT, 0, stream>>>(A, lda, B, ldb, out, ldo, (int)M, (int)N, (int)K, kps, bptr, acc_flag, slab);          \
+            if (tm == 2 && tn == 2) k_gemm_bf16x3<AT, BT, 2, 2><<<grid, GT, 0, stream>>>(A, lda, B, ldb, out, ldo, (int)M, (int)N, (int)K, kps, bptr, acc_flag, slab); \
+            else if (tm == 2) k_gemm_bf16x3<AT, BT, 2, 1><<<grid, GT, 0, stream>>>(A, lda, B, ldb, out, ldo, (int)M, (int)N, (int)K, kps, bptr, acc_flag, slab);       \
+            else if (tn == 2) k_gemm_bf16x3<AT, BT, 1, 2><<<grid, GT, 0, stream>>>(A, lda, B, ldb, out, ldo, (int)M, (int)N, (int)K, kps, bptr, acc_flag, slab);       \
+            else k_gemm_bf16x3<AT, BT, 1, 1><<<grid, GT, 0, stream>>>(A, lda, B, ldb, out, ldo, (int)M, (int)N, (int)K, kps, bptr, acc_flag, slab);                    \
         } else if (tm == 2 && tn == 2) k_gemm_f32<AT, BT, 2, 2><<<grid, GT, 0, stream>>>(A, lda, B, ldb, out, ldo, (int)M, (int)N, (int)K, kps, bptr, acc_flag, slab); \
         else if (tm == 2) k_gemm_f32<AT, BT, 2, 1><<<grid, GT, 0, stream>>>(A, lda, B, ldb, out, ldo, (int)M, (int)N, (int)K, kps, bptr, acc_flag, slab);       \
         else if (tn == 2) k_gemm_f32<AT, BT, 1, 2><<<grid, GT, 0, stream>>>(A, lda, B, ldb, out, ldo, (int)M, (int)N, (int)K, kps, bptr, acc_flag, slab);       \
