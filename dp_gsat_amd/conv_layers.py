@@ -1,7 +1,7 @@
 """Conv operators with the reference's call signature ``conv(x, edge_index, edge_attr=None, edge_atten=None)``.
 
 Message passing (gather, mask, reduce, and its backward) runs in the HIP kernels behind
-:mod:`dp_gsat_amd.ops`; the dense node update stays a library GEMM (torch -> hipBLASLt).
+:mod:`dp_gsat_amd.ops`; large dense node updates run on the split-bf16 MFMA GEMM of the same library, small ones on hipBLASLt.
 """
 from __future__ import annotations
 
