@@ -278,7 +278,7 @@ def aggregation_roofline(wl, data, dev, reps=30, rounds=5):
 # ------------------------------------------------------------------------------------------------
 # CPU baseline: the oracle (plain-PyTorch restatement of the reference op sequence) on the host cores
 # ------------------------------------------------------------------------------------------------
-def cpu_baseline(wl, name, seed, sample_graphs, steps=3):
+def cpu_baseline(wl, name, seed, sample_graphs, steps=5):
     from oracle import bookkeeping as bk
     from oracle import modules as om
     from oracle import ops as oops
@@ -436,7 +436,12 @@ def main():
         hot.reuse_index = True
         roof = aggregation_roofline(wl, data, dev)
         if not args.no_cpu_baseline and world == 1:          # reported at N=1 only
-            sample = args.cpu_sample_graphs or max(1, wl["graphs"] // 8)
+            # bounded sample: leading graphs up to ~60k directed edges (half of the C3 batch: ~10 s of host work over the two
+            # thread settings), never more than half the batch, at least one graph
+            from dp_gsat_amd.dist import edges_per_graph
+            cum = np.cumsum(np.asarray(edges_per_graph(host_batch), dtype=np.int64))
+            fit = int(np.searchsorted(cum, 60_000, side="right"))
+            sample = args.cpu_sample_graphs or max(1, min(fit, wl["graphs"] // 2))
             cpu = cpu_baseline(wl, args.workload, args.seed, sample)
     if distributed:
         dist.barrier()
