@@ -353,6 +353,7 @@ def main():
     ap.add_argument("--no-full-step", action="store_true")
     ap.add_argument("--cpu-sample-graphs", type=int, default=0)
     ap.add_argument("--graph", action="store_true", help="capture the scope-A step into a hipGraph (torch.cuda.graph) and time replays")
+    ap.add_argument("--sync-free", action="store_true", help="eager launches, but no device->host read inside the step (dp_gsat_amd.set_sync_free)")
     ap.add_argument("--roofline-only", action="store_true", help="only run the aggregation-kernel roofline leg (for rocprofv3 --pmc passes)")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only to rehearse N>1 on one GPU)")
     args = ap.parse_args()
@@ -409,7 +410,7 @@ def main():
         return graph.replay
 
     import dp_gsat_amd as G
-    G.set_sync_free(bool(args.graph))            # graph mode: no host read-backs inside the step, so it is capturable
+    G.set_sync_free(bool(args.graph or args.sync_free))    # graph mode: no host read-backs inside the step, so it is capturable
     step_fn = captured(hot.step) if args.graph else hot.step
     dt = timed(step_fn, args.steps, args.warmup, dev, distributed)
     e_local = torch.tensor([float(data.num_edges), float(data.num_nodes)], dtype=torch.float64, device=dev)
@@ -453,7 +454,7 @@ def main():
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": wl["desc"], "graphs_per_gpu": wl["graphs"], "nodes_total": int(n_total), "edges_total": int(e_total),
                        "hidden": wl["H"], "layers": wl["L"], "attention": "edge" if wl["edge_att"] else "node",
-                       "parallelism": f"dp{world}", "index_rebuilt_every_step": not args.reuse_index, "hipgraph": bool(args.graph)},
+                       "parallelism": f"dp{world}", "index_rebuilt_every_step": not args.reuse_index, "hipgraph": bool(args.graph), "sync_free": bool(args.graph or args.sync_free)},
             "roofline": roof, "cpu_baseline": cpu, "full_step": full,
         }
         if cpu:
