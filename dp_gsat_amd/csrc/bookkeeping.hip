@@ -104,6 +104,85 @@ static size_t chunk_scan_temp_bytes(int64_t n) {
     return align_up(tb, 256) + 256;
 }
 
+// ---- both CSRs of a batch from ONE sort ----------------------------------------------------------------------------
+// keys[i] = dst[i] for i < E (by-destination half), N + src[i - E] for i >= E (by-source half); ids = edge id.  A stable sort
+// leaves the halves in [0,E) and [E,2E), each ordered by (row, edge id) -- the same order two separate sorts produce -- in
+// half the launches (the builds are chains of ~5 us dependent launches, not bandwidth).
+__global__ void k_make_pair_keys(const int64_t* __restrict__ ei, int64_t E, int64_t N, uint32_t* __restrict__ keys,
+                                 int32_t* __restrict__ ids, int32_t* __restrict__ src32, int32_t* __restrict__ dst32, int32_t* err) {
+    int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= E) return;
+    int64_t s = ei[e], d = ei[E + e];
+    if (s < 0 || s >= N) { atomicAdd(err, 1); s = N - 1; }
+    if (d < 0 || d >= N) { atomicAdd(err, 1); d = N - 1; }
+    keys[e] = (uint32_t)d;
+    keys[E + e] = (uint32_t)(N + s);
+    ids[e] = (int32_t)e;
+    ids[E + e] = (int32_t)e;
+    if (src32) src32[e] = (int32_t)ei[e];
+    if (dst32) dst32[e] = (int32_t)ei[E + e];
+}
+
+__global__ void k_pair_rowptrs(const uint32_t* __restrict__ sorted, int64_t E, int64_t N, int32_t* __restrict__ rowptr_dst,
+                               int32_t* __restrict__ rowptr_src) {
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i > 2 * N + 1) return;
+    const bool second = i > N;
+    const int64_t r = second ? i - (N + 1) : i;                 // row of its half, in [0, N]
+    const int64_t target = second ? N + r : r;
+    int64_t lo = 0, hi = 2 * E;
+    while (lo < hi) {
+        int64_t mid = (lo + hi) >> 1;
+        if ((int64_t)sorted[mid] < target) lo = mid + 1; else hi = mid;
+    }
+    if (second) rowptr_src[r] = (int32_t)(lo - E); else rowptr_dst[r] = (int32_t)lo;
+}
+
+__global__ void k_pair_gather(const int64_t* __restrict__ ei, const int32_t* __restrict__ perm, int64_t E,
+                              int32_t* __restrict__ src_by_dst, int32_t* __restrict__ eid_by_dst, int32_t* __restrict__ dst_by_src,
+                              int32_t* __restrict__ eid_by_src, int32_t* __restrict__ slot_of_eid) {
+    int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= 2 * E) return;
+    const int32_t e = perm[k];
+    if (k < E) { eid_by_dst[k] = e; src_by_dst[k] = (int32_t)ei[e]; slot_of_eid[e] = (int32_t)k; }
+    else { eid_by_src[k - E] = e; dst_by_src[k - E] = (int32_t)ei[E + e]; }
+}
+
+__global__ void k_slot_map(const int32_t* __restrict__ eid_by_src, const int32_t* __restrict__ slot_of_eid, int64_t E,
+                           int32_t* __restrict__ slot_dst_of_srcslot) {
+    int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (k < E) slot_dst_of_srcslot[k] = slot_of_eid[eid_by_src[k]];
+}
+
+struct ChunkCount2 {     // ChunkCount over the rows of both CSRs laid end to end: [0, N] by-destination, [N+1, 2N+1] by-source
+    const int32_t* rp_dst;
+    const int32_t* rp_src;
+    int num_rows;
+    __host__ __device__ int operator()(int i) const {
+        const int32_t* rp = i > num_rows ? rp_src : rp_dst;
+        const int r = i > num_rows ? i - (num_rows + 1) : i;
+        if (r >= num_rows) return 0;
+        const int deg = rp[r + 1] - rp[r];
+        return deg > GSAT_LONG_ROW_EDGES ? (deg + GSAT_LONG_ROW_EDGES - 1) / GSAT_LONG_ROW_EDGES : 0;
+    }
+};
+
+__global__ void k_split_chunk_ptrs(const int32_t* __restrict__ scan, int64_t N, int32_t* __restrict__ chunk_ptr_dst,
+                                   int32_t* __restrict__ chunk_ptr_src) {
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i > N) return;
+    chunk_ptr_dst[i] = scan[i];
+    chunk_ptr_src[i] = scan[N + 1 + i] - scan[N + 1];
+}
+
+static size_t chunk2_scan_temp_bytes(int64_t n) {
+    size_t tb = 0;
+    auto in = rocprim::make_transform_iterator(rocprim::make_counting_iterator<int>(0), ChunkCount2{nullptr, nullptr, 0});
+    int32_t* out = nullptr;
+    (void)rocprim::exclusive_scan(nullptr, tb, in, out, 0, (size_t)(2 * n + 2), rocprim::plus<int>(), (hipStream_t)0);
+    return align_up(tb, 256) + 256;
+}
+
 template <class K>
 static size_t sort_temp_bytes(int64_t n) {
     size_t tb = 0;
@@ -197,6 +276,58 @@ int gsat_reverse_edge_perm(const int64_t* edge_index, int64_t E, int64_t N, int3
     k_pair_reverse<<<ceil_div(E, B), B, 0, stream>>>(ks, kts, p, q, E, rev, flags);
     GSAT_LAUNCH_CHECK();
     k_finish_flags<<<1, 1, 0, stream>>>(flags);
+    GSAT_LAUNCH_CHECK();
+    return GSAT_OK;
+}
+
+size_t gsat_csr_pair_workspace_bytes(int64_t E, int64_t N) {
+    const size_t e2 = (size_t)(E > 0 ? 2 * E : 2), n2 = (size_t)(N > 0 ? 2 * N + 2 : 2);
+    return 4 * align_up(e2 * 4, 256) + align_up((size_t)(E > 0 ? E : 1) * 4, 256) + align_up(n2 * 4, 256) + sort_temp_bytes<uint32_t>(2 * E) +
+           chunk2_scan_temp_bytes(N);
+}
+
+int gsat_build_csr_pair(const int64_t* edge_index, int64_t E, int64_t N, int32_t* rowptr_dst, int32_t* src_by_dst, int32_t* eid_by_dst,
+                        int32_t* rowptr_src, int32_t* dst_by_src, int32_t* eid_by_src, int32_t* slot_dst_of_srcslot,
+                        int32_t* chunk_ptr_dst, int32_t* chunk_ptr_src, int32_t* src32, int32_t* dst32, int32_t* err_flag,
+                        void* workspace, size_t ws_bytes, void* stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    GSAT_REQUIRE(E >= 0 && N >= 0 && rowptr_dst && rowptr_src && chunk_ptr_dst && chunk_ptr_src && err_flag, GSAT_ERR_ARG,
+                 "gsat_build_csr_pair: bad argument");
+    GSAT_REQUIRE(2 * E < (1ll << 31) && 2 * N + 2 < (1ll << 31), GSAT_ERR_UNSUPPORTED, "gsat_build_csr_pair: >2^30 entries");
+    if (E == 0) {
+        GSAT_CHECK_HIP(hipMemsetAsync(rowptr_dst, 0, (size_t)(N + 1) * sizeof(int32_t), stream));
+        GSAT_CHECK_HIP(hipMemsetAsync(rowptr_src, 0, (size_t)(N + 1) * sizeof(int32_t), stream));
+        GSAT_CHECK_HIP(hipMemsetAsync(chunk_ptr_dst, 0, (size_t)(N + 1) * sizeof(int32_t), stream));
+        GSAT_CHECK_HIP(hipMemsetAsync(chunk_ptr_src, 0, (size_t)(N + 1) * sizeof(int32_t), stream));
+        return GSAT_OK;
+    }
+    GSAT_REQUIRE(edge_index && src_by_dst && eid_by_dst && dst_by_src && eid_by_src && slot_dst_of_srcslot && N > 0, GSAT_ERR_ARG,
+                 "gsat_build_csr_pair: null pointer");
+    Arena ar(workspace, ws_bytes);
+    uint32_t* keys_in = ar.take<uint32_t>(2 * E);
+    uint32_t* keys_out = ar.take<uint32_t>(2 * E);
+    int32_t* ids = ar.take<int32_t>(2 * E);
+    int32_t* perm = ar.take<int32_t>(2 * E);
+    int32_t* slot_of_eid = ar.take<int32_t>(E);
+    int32_t* scan = ar.take<int32_t>(2 * N + 2);
+    size_t tb = sort_temp_bytes<uint32_t>(2 * E), tc = chunk2_scan_temp_bytes(N);
+    char* temp = ar.take<char>(tb);
+    char* temp2 = ar.take<char>(tc);
+    GSAT_REQUIRE(ar.ok() && temp && temp2, GSAT_ERR_WORKSPACE, "gsat_build_csr_pair: workspace %zu < %zu", ws_bytes, ar.off);
+    const int B = 256;
+    k_make_pair_keys<<<ceil_div(E, B), B, 0, stream>>>(edge_index, E, N, keys_in, ids, src32, dst32, err_flag);
+    GSAT_LAUNCH_CHECK();
+    const int end_bit = bits_for((uint64_t)(2 * N - 1));
+    GSAT_CHECK_HIP(rocprim::radix_sort_pairs(temp, tb, keys_in, keys_out, ids, perm, (size_t)(2 * E), 0, (unsigned)end_bit, stream));
+    k_pair_rowptrs<<<ceil_div(2 * N + 2, B), B, 0, stream>>>(keys_out, E, N, rowptr_dst, rowptr_src);
+    GSAT_LAUNCH_CHECK();
+    k_pair_gather<<<ceil_div(2 * E, B), B, 0, stream>>>(edge_index, perm, E, src_by_dst, eid_by_dst, dst_by_src, eid_by_src, slot_of_eid);
+    GSAT_LAUNCH_CHECK();
+    k_slot_map<<<ceil_div(E, B), B, 0, stream>>>(eid_by_src, slot_of_eid, E, slot_dst_of_srcslot);
+    GSAT_LAUNCH_CHECK();
+    auto in = rocprim::make_transform_iterator(rocprim::make_counting_iterator<int>(0), ChunkCount2{rowptr_dst, rowptr_src, (int)N});
+    GSAT_CHECK_HIP(rocprim::exclusive_scan(temp2, tc, in, scan, 0, (size_t)(2 * N + 2), rocprim::plus<int>(), stream));
+    k_split_chunk_ptrs<<<ceil_div(N + 1, B), B, 0, stream>>>(scan, N, chunk_ptr_dst, chunk_ptr_src);
     GSAT_LAUNCH_CHECK();
     return GSAT_OK;
 }

@@ -8,6 +8,7 @@ destination and by source, the reverse-edge permutation and the per-graph segmen
 """
 from __future__ import annotations
 
+import os
 from collections import OrderedDict
 from typing import Optional
 
@@ -49,42 +50,51 @@ class BatchIndex:
         self.device = edge_index.device
         dev = self.device
         E, N = self.E, self.N
-        ws_bytes = max(call_size("gsat_csr_workspace_bytes", E, N), 256)
-        ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
         self._err = torch.zeros(4, dtype=torch.int32, device=dev)
-        src, dst = self.edge_index[0], self.edge_index[1]
-        # CSR by destination: the forward aggregation order
+        # Both CSRs -- by destination (the forward aggregation order) and by source (the transposed structure of every
+        # backward) -- their long-row (hub) chunk lists (empty for molecule-like graphs, built without a host sync), the
+        # by-source-slot -> by-destination-slot map and int32 copies of the two edge_index rows: one library call, one sort.
         self.rowptr_dst = torch.empty(N + 1, dtype=torch.int32, device=dev)
-        self.src_by_dst = _i32(E, dev)
-        self.eid_by_dst = _i32(E, dev)
-        call("gsat_build_csr", ptr(dst), ptr(src), E, N, ptr(self.rowptr_dst), ptr(self.src_by_dst),
-             ptr(self.eid_by_dst), ptr(self._err), ptr(ws), ws_bytes, stream())
-        # CSR by source: the transposed structure used by every backward
         self.rowptr_src = torch.empty(N + 1, dtype=torch.int32, device=dev)
-        self.dst_by_src = _i32(E, dev)
-        self.eid_by_src = _i32(E, dev)
-        call("gsat_build_csr", ptr(src), ptr(dst), E, N, ptr(self.rowptr_src), ptr(self.dst_by_src),
-             ptr(self.eid_by_src), ptr(self._err), ptr(ws), ws_bytes, stream())
-        # long-row (hub) chunk lists of both CSRs: empty for molecule-like graphs, built without a host sync
-        cws_bytes = max(call_size("gsat_row_chunks_workspace_bytes", N), 256)
-        cws = torch.empty(cws_bytes, dtype=torch.uint8, device=dev)
         self.chunk_ptr_dst = torch.empty(N + 1, dtype=torch.int32, device=dev)
         self.chunk_ptr_src = torch.empty(N + 1, dtype=torch.int32, device=dev)
-        call("gsat_row_chunks", ptr(self.rowptr_dst), N, ptr(self.chunk_ptr_dst), ptr(cws), cws_bytes, stream())
-        call("gsat_row_chunks", ptr(self.rowptr_src), N, ptr(self.chunk_ptr_src), ptr(cws), cws_bytes, stream())
+        ints = torch.empty(7, max((E + 3) // 4 * 4, 4), dtype=torch.int32, device=dev)      # 16-byte aligned rows
+        (self.src_by_dst, self.eid_by_dst, self.dst_by_src, self.eid_by_src, self._slot_dst_of_srcslot, self.src32,
+         self.dst32) = (ints[i, :E] for i in range(7))
+        if os.environ.get("GSAT_CSR_PAIR", "1") == "0":          # A/B switch: the two-sort build through the single-CSR entry points
+            src, dst = self.edge_index[0], self.edge_index[1]
+            wb = max(call_size("gsat_csr_workspace_bytes", E, N), 256)
+            w1 = torch.empty(wb, dtype=torch.uint8, device=dev)
+            call("gsat_build_csr", ptr(dst), ptr(src), E, N, ptr(self.rowptr_dst), ptr(self.src_by_dst), ptr(self.eid_by_dst),
+                 ptr(self._err), ptr(w1), wb, stream())
+            call("gsat_build_csr", ptr(src), ptr(dst), E, N, ptr(self.rowptr_src), ptr(self.dst_by_src), ptr(self.eid_by_src),
+                 ptr(self._err), ptr(w1), wb, stream())
+            cb = max(call_size("gsat_row_chunks_workspace_bytes", N), 256)
+            w2 = torch.empty(cb, dtype=torch.uint8, device=dev)
+            call("gsat_row_chunks", ptr(self.rowptr_dst), N, ptr(self.chunk_ptr_dst), ptr(w2), cb, stream())
+            call("gsat_row_chunks", ptr(self.rowptr_src), N, ptr(self.chunk_ptr_src), ptr(w2), cb, stream())
+            call("gsat_narrow_i64", ptr(src), E, ptr(self.src32), stream())
+            call("gsat_narrow_i64", ptr(dst), E, ptr(self.dst32), stream())
+            if E:
+                inv = torch.empty(E, dtype=torch.int32, device=dev)
+                inv[self.eid_by_dst.long()] = torch.arange(E, dtype=torch.int32, device=dev)
+                self._slot_dst_of_srcslot.copy_(inv[self.eid_by_src.long()])
+            self._partials, self._long = {}, None
+            self._checked, self._rev, self._rev_dev, self._rev_flags, self._undirected, self._graphs = False, None, None, None, None, {}
+            return
+        ws_bytes = max(call_size("gsat_csr_pair_workspace_bytes", E, N), 256)
+        ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
+        call("gsat_build_csr_pair", ptr(self.edge_index), E, N, ptr(self.rowptr_dst), ptr(self.src_by_dst), ptr(self.eid_by_dst),
+             ptr(self.rowptr_src), ptr(self.dst_by_src), ptr(self.eid_by_src), ptr(self._slot_dst_of_srcslot),
+             ptr(self.chunk_ptr_dst), ptr(self.chunk_ptr_src), ptr(self.src32), ptr(self.dst32), ptr(self._err), ptr(ws), ws_bytes,
+             stream())
         self._partials = {}
         self._long = None
-        # int32 copies of the two edge_index rows (original edge order) for the per-edge kernels
-        self.src32 = _i32(E, dev)
-        self.dst32 = _i32(E, dev)
-        call("gsat_narrow_i64", ptr(src.contiguous()), E, ptr(self.src32), stream())
-        call("gsat_narrow_i64", ptr(dst.contiguous()), E, ptr(self.dst32), stream())
         self._checked = False
         self._rev = None
         self._rev_dev = None
         self._rev_flags = None
         self._undirected = None
-        self._slot_dst_of_srcslot = None
         self._graphs = {}
 
     @property
@@ -169,10 +179,6 @@ class BatchIndex:
     @property
     def slot_dst_of_srcslot(self) -> torch.Tensor:
         """For slot k of the by-source CSR, the slot of the same edge in the by-destination CSR."""
-        if self._slot_dst_of_srcslot is None:
-            inv = torch.empty(self.E, dtype=torch.int32, device=self.device)
-            inv[self.eid_by_dst.long()] = torch.arange(self.E, dtype=torch.int32, device=self.device)
-            self._slot_dst_of_srcslot = inv[self.eid_by_src.long()].contiguous()
         return self._slot_dst_of_srcslot
 
     # -- per-graph segments ----------------------------------------------------------------------

@@ -60,6 +60,20 @@ int gsat_build_csr(const int64_t* rows, const int64_t* other, int64_t num_edges,
                    void* workspace, size_t workspace_bytes, void* stream);
 
 /*
+ * Both CSRs of one collated batch from ONE stable sort of 2E (row, edge id) keys -- by destination (forward aggregation) and by
+ * source (every backward) -- plus what the host side derives from them: the hub-row chunk lists of both (gsat_row_chunks), the
+ * by-source-slot -> by-destination-slot map used by the PNA backward, and int32 copies of the two edge_index rows.  Results are
+ * identical to two gsat_build_csr calls (same stable order); the point is half the dependent launches per fresh batch.
+ * edge_index [2,E] int64 (row 0 = source, row 1 = target).  replaces: the scatter index of MessagePassing.propagate
+ * (src/models/conv_layers.py:21,44,163) for a whole batch.  workspace: gsat_csr_pair_workspace_bytes(E, N).
+ */
+size_t gsat_csr_pair_workspace_bytes(int64_t E, int64_t num_nodes);
+int gsat_build_csr_pair(const int64_t* edge_index, int64_t E, int64_t num_nodes, int32_t* rowptr_dst, int32_t* src_by_dst,
+                        int32_t* eid_by_dst, int32_t* rowptr_src, int32_t* dst_by_src, int32_t* eid_by_src,
+                        int32_t* slot_dst_of_srcslot, int32_t* chunk_ptr_dst, int32_t* chunk_ptr_src, int32_t* src32,
+                        int32_t* dst32, int32_t* err_flag, void* workspace, size_t workspace_bytes, void* stream);
+
+/*
  * rev[k] = id of the edge (dst_k, src_k); flags[0] = 1 iff the edge multiset equals its transpose
  * (is_undirected), flags[1] = number of sorted positions where edge and transposed keys differ.
  * Pairing rule for duplicate edges: stable (key, edge id) order on both sides.
