@@ -51,23 +51,23 @@ __global__ void k_gather_narrow(const int64_t* __restrict__ src, const int32_t* 
     if (k < n) out[k] = (int32_t)src[perm[k]];
 }
 
-__global__ void k_make_edge_keys(const int64_t* __restrict__ ei, int64_t E, int64_t N,
-                                 uint64_t* __restrict__ k, uint64_t* __restrict__ kt, int32_t* __restrict__ ids) {
+__global__ void k_make_edge_keys2(const int64_t* __restrict__ ei, int64_t E, int64_t N, int key_bits, uint64_t* __restrict__ k,
+                                  int32_t* __restrict__ ids) {
     int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (e >= E) return;
-    uint64_t s = (uint64_t)ei[e], d = (uint64_t)ei[E + e];
+    const uint64_t s = (uint64_t)ei[e], d = (uint64_t)ei[E + e];
     k[e] = s * (uint64_t)N + d;
-    kt[e] = d * (uint64_t)N + s;
+    k[E + e] = (d * (uint64_t)N + s) | (1ull << key_bits);
     ids[e] = (int32_t)e;
+    ids[E + e] = (int32_t)e;
 }
 
-__global__ void k_pair_reverse(const uint64_t* __restrict__ ks, const uint64_t* __restrict__ kts,
-                               const int32_t* __restrict__ p, const int32_t* __restrict__ q, int64_t E,
-                               int32_t* __restrict__ rev, int32_t* __restrict__ flags) {
+__global__ void k_pair_reverse2(const uint64_t* __restrict__ sorted, const int32_t* __restrict__ pq, int64_t E, int key_bits,
+                                int32_t* __restrict__ rev, int32_t* __restrict__ flags) {
     int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= E) return;
-    rev[q[i]] = p[i];
-    if (ks[i] != kts[i]) atomicAdd(&flags[1], 1);
+    rev[pq[E + i]] = pq[i];
+    if (sorted[i] != (sorted[E + i] & ~(1ull << key_bits))) atomicAdd(&flags[1], 1);
 }
 
 __global__ void k_finish_flags(int32_t* flags) { flags[0] = flags[1] == 0 ? 1 : 0; }
@@ -207,8 +207,8 @@ size_t gsat_csr_workspace_bytes(int64_t E, int64_t /*num_rows*/) {
 }
 
 size_t gsat_rev_workspace_bytes(int64_t E) {
-    size_t e = (size_t)(E > 0 ? E : 1);
-    return 4 * align_up(e * 8, 256) + 3 * align_up(e * 4, 256) + sort_temp_bytes<uint64_t>(E);
+    size_t e2 = (size_t)(E > 0 ? 2 * E : 2);
+    return 2 * align_up(e2 * 8, 256) + 2 * align_up(e2 * 4, 256) + sort_temp_bytes<uint64_t>(2 * E);
 }
 
 int gsat_build_csr(const int64_t* rows, const int64_t* other, int64_t E, int64_t num_rows, int32_t* rowptr,
@@ -248,7 +248,7 @@ int gsat_reverse_edge_perm(const int64_t* edge_index, int64_t E, int64_t N, int3
                            void* workspace, size_t ws_bytes, void* stream_) {
     hipStream_t stream = (hipStream_t)stream_;
     GSAT_REQUIRE(E >= 0 && N >= 0 && flags, GSAT_ERR_ARG, "gsat_reverse_edge_perm: bad argument");
-    GSAT_REQUIRE(E < (1ll << 31) && N < (1ll << 31), GSAT_ERR_UNSUPPORTED, "gsat_reverse_edge_perm: >2^31 entries");
+    GSAT_REQUIRE(E < (1ll << 30) && N < (1ll << 31), GSAT_ERR_UNSUPPORTED, "gsat_reverse_edge_perm: >2^30 edges");
     GSAT_CHECK_HIP(hipMemsetAsync(flags, 0, 2 * sizeof(int32_t), stream));
     if (E == 0) {
         k_finish_flags<<<1, 1, 0, stream>>>(flags);
@@ -256,24 +256,23 @@ int gsat_reverse_edge_perm(const int64_t* edge_index, int64_t E, int64_t N, int3
         return GSAT_OK;
     }
     GSAT_REQUIRE(edge_index && rev && N > 0, GSAT_ERR_ARG, "gsat_reverse_edge_perm: null pointer");
+    // one stable sort of 2E keys: [0,E) the edge keys src*N+dst, [E,2E) the transposed keys dst*N+src with a half bit on top;
+    // sorted position i of the first half pairs with position i of the second half (same launches as ONE sort)
     Arena ar(workspace, ws_bytes);
-    uint64_t* k = ar.take<uint64_t>(E);
-    uint64_t* kt = ar.take<uint64_t>(E);
-    uint64_t* ks = ar.take<uint64_t>(E);
-    uint64_t* kts = ar.take<uint64_t>(E);
-    int32_t* ids = ar.take<int32_t>(E);
-    int32_t* p = ar.take<int32_t>(E);
-    int32_t* q = ar.take<int32_t>(E);
-    size_t tb = sort_temp_bytes<uint64_t>(E);
+    uint64_t* kin = ar.take<uint64_t>(2 * E);
+    uint64_t* kout = ar.take<uint64_t>(2 * E);
+    int32_t* ids = ar.take<int32_t>(2 * E);
+    int32_t* pq = ar.take<int32_t>(2 * E);
+    size_t tb = sort_temp_bytes<uint64_t>(2 * E);
     char* temp = ar.take<char>(tb);
     GSAT_REQUIRE(ar.ok() && temp, GSAT_ERR_WORKSPACE, "gsat_reverse_edge_perm: workspace %zu < %zu", ws_bytes, ar.off);
     const int B = 256;
-    k_make_edge_keys<<<ceil_div(E, B), B, 0, stream>>>(edge_index, E, N, k, kt, ids);
+    const int key_bits = bits_for((uint64_t)N * (uint64_t)N - 1);
+    GSAT_REQUIRE(key_bits < 63, GSAT_ERR_UNSUPPORTED, "gsat_reverse_edge_perm: N too large");
+    k_make_edge_keys2<<<ceil_div(E, B), B, 0, stream>>>(edge_index, E, N, key_bits, kin, ids);
     GSAT_LAUNCH_CHECK();
-    int end_bit = bits_for((uint64_t)N * (uint64_t)N - 1);
-    GSAT_CHECK_HIP(rocprim::radix_sort_pairs(temp, tb, k, ks, ids, p, (size_t)E, 0, (unsigned)end_bit, stream));
-    GSAT_CHECK_HIP(rocprim::radix_sort_pairs(temp, tb, kt, kts, ids, q, (size_t)E, 0, (unsigned)end_bit, stream));
-    k_pair_reverse<<<ceil_div(E, B), B, 0, stream>>>(ks, kts, p, q, E, rev, flags);
+    GSAT_CHECK_HIP(rocprim::radix_sort_pairs(temp, tb, kin, kout, ids, pq, (size_t)(2 * E), 0, (unsigned)(key_bits + 1), stream));
+    k_pair_reverse2<<<ceil_div(E, B), B, 0, stream>>>(kout, pq, E, key_bits, rev, flags);
     GSAT_LAUNCH_CHECK();
     k_finish_flags<<<1, 1, 0, stream>>>(flags);
     GSAT_LAUNCH_CHECK();
