@@ -35,6 +35,7 @@ SIGNATURES = {
     "gsat_pna_bwd": (INT, [P, P, P, P, P, P, P, I64, I64, P, INT, P, INT, F32, F32, P, P, P, P, P]),
     "gsat_csr_pair_workspace_bytes": (SZ, [I64, I64]),
     "gsat_build_csr_pair": (INT, [P, I64, I64] + [P] * 12 + [P, SZ, P]),
+    "gsat_segment_ptr32": (INT, [P, I64, I64, P, P, P, P]),
     "gsat_bn_workspace_floats": (SZ, [I64, I64]),
     "gsat_bn_fwd": (INT, [P, P, P, P, P, I64, I64, INT, F32, F32, INT, P, P, P, P, P]),
     "gsat_bn_bwd": (INT, [P, P, P, P, P, P, I64, I64, INT, INT, P, P, P, P, P]),

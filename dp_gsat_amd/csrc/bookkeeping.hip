@@ -80,6 +80,16 @@ __global__ void k_check_sorted(const int64_t* __restrict__ ids, int64_t n, int64
     if (bad) atomicAdd(flags, 1);
 }
 
+// k_check_sorted + the int32 copy of the ids in one pass
+__global__ void k_check_sorted_narrow(const int64_t* __restrict__ ids, int64_t n, int64_t num_seg, int32_t* flags, int32_t* __restrict__ ids32) {
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    int64_t v = ids[i];
+    bool bad = v < 0 || v >= num_seg || (i > 0 && ids[i - 1] > v);
+    if (bad) atomicAdd(flags, 1);
+    ids32[i] = (int32_t)v;
+}
+
 __global__ void k_gather_i64(const int64_t* __restrict__ table, const int64_t* __restrict__ index, int64_t n,
                              int64_t* __restrict__ out) {
     int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -352,6 +362,22 @@ int gsat_segment_ptr(const int64_t* seg_ids, int64_t n, int64_t num_seg, int32_t
     if (n > 0) {
         GSAT_REQUIRE(seg_ids, GSAT_ERR_ARG, "gsat_segment_ptr: null ids");
         k_check_sorted<<<ceil_div(n, B), B, 0, stream>>>(seg_ids, n, num_seg, flags);
+        GSAT_LAUNCH_CHECK();
+    }
+    k_lower_bounds<int64_t><<<ceil_div(num_seg + 1, B), B, 0, stream>>>(seg_ids, n, num_seg, ptr);
+    GSAT_LAUNCH_CHECK();
+    return GSAT_OK;
+}
+
+int gsat_segment_ptr32(const int64_t* seg_ids, int64_t n, int64_t num_seg, int32_t* ptr, int32_t* seg_ids32, int32_t* flags, void* stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    GSAT_REQUIRE(n >= 0 && num_seg >= 0 && ptr && flags, GSAT_ERR_ARG, "gsat_segment_ptr32: bad argument");
+    GSAT_REQUIRE(n < (1ll << 31), GSAT_ERR_UNSUPPORTED, "gsat_segment_ptr32: >2^31 rows");
+    const int B = 256;
+    GSAT_CHECK_HIP(hipMemsetAsync(flags, 0, sizeof(int32_t), stream));
+    if (n > 0) {
+        GSAT_REQUIRE(seg_ids && seg_ids32, GSAT_ERR_ARG, "gsat_segment_ptr32: null ids");
+        k_check_sorted_narrow<<<ceil_div(n, B), B, 0, stream>>>(seg_ids, n, num_seg, flags, seg_ids32);
         GSAT_LAUNCH_CHECK();
     }
     k_lower_bounds<int64_t><<<ceil_div(num_seg + 1, B), B, 0, stream>>>(seg_ids, n, num_seg, ptr);

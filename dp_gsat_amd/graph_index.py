@@ -132,7 +132,7 @@ class BatchIndex:
         ws_bytes = max(call_size("gsat_rev_workspace_bytes", E), 256)
         ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
         rev = _i32(E, dev)
-        flags = torch.zeros(2, dtype=torch.int32, device=dev)
+        flags = torch.empty(2, dtype=torch.int32, device=dev)          # zeroed by the call
         call("gsat_reverse_edge_perm", ptr(self.edge_index), E, N, ptr(rev), ptr(flags), ptr(ws), ws_bytes, stream())
         self._rev_dev, self._rev_flags = rev, flags
         if _SYNC_FREE:
@@ -205,12 +205,11 @@ class GraphSegments:
             num_graphs = int(batch.max().item()) + 1 if n > 0 else 0     # reference: batch.max()+1 (sync)
         self.G = int(num_graphs)
         self.node_ptr = torch.empty(self.G + 1, dtype=torch.int32, device=dev)
-        flags = torch.zeros(1, dtype=torch.int32, device=dev)
-        call("gsat_segment_ptr", ptr(self.batch), n, self.G, ptr(self.node_ptr), ptr(flags), stream())
+        flags = torch.empty(1, dtype=torch.int32, device=dev)           # zeroed by the call
+        self.node_seg32 = _i32(n, dev)            # graph id of every node, int32 (written by the same pass that checks the order)
+        call("gsat_segment_ptr32", ptr(self.batch), n, self.G, ptr(self.node_ptr), ptr(self.node_seg32), ptr(flags), stream())
         self._flags = flags
         self._edge = None
-        self.node_seg32 = _i32(n, dev)            # graph id of every node, int32
-        call("gsat_narrow_i64", ptr(self.batch), n, ptr(self.node_seg32), stream())
 
     def check(self):
         if int(self._flags.item()) != 0:

@@ -93,6 +93,9 @@ int gsat_reverse_edge_perm(const int64_t* edge_index, int64_t num_edges, int64_t
  */
 int gsat_segment_ptr(const int64_t* seg_ids, int64_t num_rows, int64_t num_segments, int32_t* ptr,
                      int32_t* flags, void* stream);
+/* same, and also writes the int32 copy seg_ids32[n] of the ids in the checking pass (one launch fewer per batch) */
+int gsat_segment_ptr32(const int64_t* seg_ids, int64_t n, int64_t num_segments, int32_t* ptr, int32_t* seg_ids32,
+                       int32_t* flags, void* stream);
 
 /* out[e] = batch[index[e]]  (edge -> graph id, `batch[col]` of example/gsat.py:136). int64 out. */
 int gsat_gather_i64(const int64_t* table, const int64_t* index, int64_t n, int64_t* out, void* stream);
