@@ -224,10 +224,13 @@ __global__ __launch_bounds__(256) void k_head_fwd(const float* __restrict__ h2, 
     }
 }
 
-// dz[m] = dlogits[m] + datt[m] * att[m] * (1 - att[m])
+// dz[m] = dlogits[m] + datt[m] * att[m] * (1 - att[m]); the same launch zeroes the two bias gradients that are identically 0
 __global__ void k_dz(const float* __restrict__ dlogits, const float* __restrict__ datt, const float* __restrict__ att, int64_t M,
-                     float* __restrict__ dz) {
+                     float* __restrict__ dz, float* __restrict__ zero_a, int na, float* __restrict__ zero_b, int nb) {
     int64_t m = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t total = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t i = m; i < na; i += total) zero_a[i] = 0.f;
+    for (int64_t i = m; i < nb; i += total) zero_b[i] = 0.f;
     if (m >= M) return;
     float v = dlogits ? dlogits[m] : 0.f;
     if (datt) { float a = att[m]; v = fmaf(datt[m], a * (1.f - a), v); }
@@ -652,7 +655,9 @@ int gsat_attn_bwd(const gsat_attn_args* a, const gsat_attn_grads* gr, void* stre
     float* rstd2 = mean2 + (size_t)G * C2;
     const float sc = (a->training && a->p_drop > 0.f) ? 1.f / (1.f - a->p_drop) : 1.f;
 
-    k_dz<<<(unsigned)ceil_div(M, 256), 256, 0, stream>>>(gr->dlogits, gr->datt, a->att, M, dz);
+    // b1 and b2 sit in front of an InstanceNorm, which removes any per-channel constant of its segment: their
+    // gradients are exactly zero (the reference's autograd returns ~1e-7 rounding noise of a cancelling sum).
+    k_dz<<<(unsigned)ceil_div(M, 256), 256, 0, stream>>>(gr->dlogits, gr->datt, a->att, M, dz, gr->db1, (int)C1, gr->db2, (int)C2);
     GSAT_LAUNCH_CHECK();
     if ((rc = colsum(stream, dz, M, 1, gr->db3, scratch))) return rc;
     // ---- through the head and the second InstanceNorm ------------------------------------------
@@ -670,10 +675,6 @@ int gsat_attn_bwd(const gsat_attn_args* a, const gsat_attn_grads* gr, void* stre
     k_dh2<<<ew_blocks(M * (C2 / 4)), 256, 0, stream>>>(a->h2, a->b2, a->row_seg, mean2, rstd2, a->mask2, SeedRef{a->seed, a->seed_dev}, a->p_drop, a->training,
                                                        a->W3, dz, S1, S2, M, C2, dh2);
     GSAT_LAUNCH_CHECK();
-    // b1 and b2 sit in front of an InstanceNorm, which removes any per-channel constant of its segment: their
-    // gradients are exactly zero (the reference's autograd returns ~1e-7 rounding noise of a cancelling sum).
-    GSAT_CHECK_HIP(hipMemsetAsync(gr->db2, 0, sizeof(float) * C2, stream));
-    GSAT_CHECK_HIP(hipMemsetAsync(gr->db1, 0, sizeof(float) * C1, stream));
     // dW2[C2,C1] = dh2^T a1 ; da1[M,C1] = dh2 W2
     if ((rc = gemm_rm(stream, true, false, C2, C1, M, dh2, C2, a->a1, C1, 0.f, gr->dW2, C1, gws))) return rc;
     if ((rc = gemm_rm(stream, false, false, M, C1, C2, dh2, C2, a->W2, C1, 0.f, da1, C1))) return rc;

@@ -178,11 +178,13 @@ struct ChunkCount2 {     // ChunkCount over the rows of both CSRs laid end to en
 };
 
 __global__ void k_split_chunk_ptrs(const int32_t* __restrict__ scan, int64_t N, int32_t* __restrict__ chunk_ptr_dst,
-                                   int32_t* __restrict__ chunk_ptr_src) {
+                                   int32_t* __restrict__ chunk_ptr_src, int32_t* __restrict__ status) {
     int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i > N) return;
-    chunk_ptr_dst[i] = scan[i];
-    chunk_ptr_src[i] = scan[N + 1 + i] - scan[N + 1];
+    const int32_t d = scan[i], s = scan[N + 1 + i] - scan[N + 1];
+    chunk_ptr_dst[i] = d;
+    chunk_ptr_src[i] = s;
+    if (i == N) { status[1] = d; status[2] = s; }      // hub-chunk totals next to the range-error counter: one host read gets all
 }
 
 static size_t chunk2_scan_temp_bytes(int64_t n) {
@@ -336,7 +338,7 @@ int gsat_build_csr_pair(const int64_t* edge_index, int64_t E, int64_t N, int32_t
     GSAT_LAUNCH_CHECK();
     auto in = rocprim::make_transform_iterator(rocprim::make_counting_iterator<int>(0), ChunkCount2{rowptr_dst, rowptr_src, (int)N});
     GSAT_CHECK_HIP(rocprim::exclusive_scan(temp2, tc, in, scan, 0, (size_t)(2 * N + 2), rocprim::plus<int>(), stream));
-    k_split_chunk_ptrs<<<ceil_div(N + 1, B), B, 0, stream>>>(scan, N, chunk_ptr_dst, chunk_ptr_src);
+    k_split_chunk_ptrs<<<ceil_div(N + 1, B), B, 0, stream>>>(scan, N, chunk_ptr_dst, chunk_ptr_src, err_flag);
     GSAT_LAUNCH_CHECK();
     return GSAT_OK;
 }

@@ -50,7 +50,8 @@ class BatchIndex:
         self.device = edge_index.device
         dev = self.device
         E, N = self.E, self.N
-        self._err = torch.zeros(4, dtype=torch.int32, device=dev)
+        # status words, read back together: [0] range errors, [1]/[2] hub chunks by destination / source, [4] undirected, [5] unmatched
+        self._err = torch.zeros(8, dtype=torch.int32, device=dev)
         # Both CSRs -- by destination (the forward aggregation order) and by source (the transposed structure of every
         # backward) -- their long-row (hub) chunk lists (empty for molecule-like graphs, built without a host sync), the
         # by-source-slot -> by-destination-slot map and int32 copies of the two edge_index rows: one library call, one sort.
@@ -132,7 +133,7 @@ class BatchIndex:
         ws_bytes = max(call_size("gsat_rev_workspace_bytes", E), 256)
         ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
         rev = _i32(E, dev)
-        flags = torch.empty(2, dtype=torch.int32, device=dev)          # zeroed by the call
+        flags = self._err[4:6]                   # zeroed by the call; lives next to the other status words
         call("gsat_reverse_edge_perm", ptr(self.edge_index), E, N, ptr(rev), ptr(flags), ptr(ws), ws_bytes, stream())
         self._rev_dev, self._rev_flags = rev, flags
         if _SYNC_FREE:
@@ -142,16 +143,15 @@ class BatchIndex:
     def _readback(self):
         """ONE device->host read for every host-side decision of this batch: undirected flag (if the reverse permutation
         was built), hub-row chunk totals of both CSRs, out-of-range counter."""
-        parts = [self.chunk_ptr_dst[-1:], self.chunk_ptr_src[-1:], self._err[:1]]
-        if self._rev_flags is not None:
-            parts.append(self._rev_flags[:1])
-        vals = torch.cat(parts).tolist()
-        self._long = (vals[0] > 0, vals[1] > 0)
-        if vals[2] != 0:
+        if os.environ.get("GSAT_CSR_PAIR", "1") == "0":
+            self._err[1:3] = torch.cat([self.chunk_ptr_dst[-1:], self.chunk_ptr_src[-1:]])
+        vals = self._err.tolist()              # every status word of this batch in one copy, no gather kernel
+        self._long = (vals[1] > 0, vals[2] > 0)
+        if vals[0] != 0:
             raise ValueError("edge_index contains node ids outside [0, num_nodes)")
         self._checked = True
         if self._rev_flags is not None:
-            self._undirected = bool(vals[3])
+            self._undirected = bool(vals[4])
             self._rev = self._rev_dev if self._undirected else None
 
     @property
