@@ -344,8 +344,8 @@ def cpu_baseline(wl, name, seed, sample_graphs, steps=5):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--steps", type=int, default=None, help="timed steps (default 200; 10 for the c5 workloads)")
+    ap.add_argument("--warmup", type=int, default=None, help="untimed warm-up steps (default 20; 3 for the c5 workloads)")
     ap.add_argument("--workload", default="c3", choices=sorted(WORKLOADS))
     ap.add_argument("--seed", type=int, default=0)
     ap.add_argument("--reuse-index", action="store_true", help="keep the per-batch bookkeeping cached across steps")
@@ -357,6 +357,11 @@ def main():
     ap.add_argument("--roofline-only", action="store_true", help="only run the aggregation-kernel roofline leg (for rocprofv3 --pmc passes)")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only to rehearse N>1 on one GPU)")
     args = ap.parse_args()
+    big = args.workload in ("c5", "c5s")
+    if args.steps is None:
+        args.steps = 10 if big else 200          # a 1.2 ms step needs a few hundred repetitions for a stable mean
+    if args.warmup is None:
+        args.warmup = 3 if big else 20
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
