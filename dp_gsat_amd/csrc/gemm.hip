@@ -397,7 +397,9 @@ int gemm_splits(int64_t M, int64_t N, int64_t K, bool reduce_rows) {
     if (!reduce_rows) return 1;                       // only weight gradients (K = #rows) are split
     const int64_t tiles = ceil_div(M, 128) * ceil_div(N, 128);
     if (tiles >= 256 || K <= 4 * GK) return 1;
-    int64_t s = std::min<int64_t>(ceil_div(768, tiles), ceil_div(K, 8 * GK));
+    static const int div = getenv("GSAT_GEMM_SPLITK_SLABS") ? atoi(getenv("GSAT_GEMM_SPLITK_SLABS")) : 8;     // min 32-k slabs per split
+    static const int target = getenv("GSAT_GEMM_SPLITK_BLOCKS") ? atoi(getenv("GSAT_GEMM_SPLITK_BLOCKS")) : 768;
+    int64_t s = std::min<int64_t>(ceil_div(target, tiles), ceil_div(K, (int64_t)div * GK));
     return (int)std::max<int64_t>(1, std::min<int64_t>(s, 512));
 }
 
