@@ -80,14 +80,25 @@ __global__ void k_check_sorted(const int64_t* __restrict__ ids, int64_t n, int64
     if (bad) atomicAdd(flags, 1);
 }
 
-// k_check_sorted + the int32 copy of the ids in one pass
-__global__ void k_check_sorted_narrow(const int64_t* __restrict__ ids, int64_t n, int64_t num_seg, int32_t* flags, int32_t* __restrict__ ids32) {
+// order / range check, int32 copy of the ids and the segment pointers in one launch (thread i < n: element i; thread r <= num_seg:
+// boundary r)
+__global__ void k_segments(const int64_t* __restrict__ ids, int64_t n, int64_t num_seg, int32_t* flags, int32_t* __restrict__ ids32,
+                           int32_t* __restrict__ ptr) {
     int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    int64_t v = ids[i];
-    bool bad = v < 0 || v >= num_seg || (i > 0 && ids[i - 1] > v);
-    if (bad) atomicAdd(flags, 1);
-    ids32[i] = (int32_t)v;
+    if (i < n) {
+        int64_t v = ids[i];
+        bool bad = v < 0 || v >= num_seg || (i > 0 && ids[i - 1] > v);
+        if (bad) atomicAdd(flags, 1);
+        ids32[i] = (int32_t)v;
+    }
+    if (i <= num_seg) {
+        int64_t lo = 0, hi = n;
+        while (lo < hi) {
+            int64_t mid = (lo + hi) >> 1;
+            if (ids[mid] < i) lo = mid + 1; else hi = mid;
+        }
+        ptr[i] = (int32_t)lo;
+    }
 }
 
 __global__ void k_gather_i64(const int64_t* __restrict__ table, const int64_t* __restrict__ index, int64_t n,
@@ -148,20 +159,25 @@ __global__ void k_pair_rowptrs(const uint32_t* __restrict__ sorted, int64_t E, i
     if (second) rowptr_src[r] = (int32_t)(lo - E); else rowptr_dst[r] = (int32_t)lo;
 }
 
-__global__ void k_pair_gather(const int64_t* __restrict__ ei, const int32_t* __restrict__ perm, int64_t E,
-                              int32_t* __restrict__ src_by_dst, int32_t* __restrict__ eid_by_dst, int32_t* __restrict__ dst_by_src,
-                              int32_t* __restrict__ eid_by_src, int32_t* __restrict__ slot_of_eid) {
+__global__ void k_pair_gather(const int64_t* __restrict__ ei, const int32_t* __restrict__ perm, int64_t E, int64_t num_nodes,
+                              const int32_t* __restrict__ rowptr_dst, int32_t* __restrict__ src_by_dst, int32_t* __restrict__ eid_by_dst,
+                              int32_t* __restrict__ dst_by_src, int32_t* __restrict__ eid_by_src, int32_t* __restrict__ slot_dst_of_srcslot) {
     int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (k >= 2 * E) return;
     const int32_t e = perm[k];
-    if (k < E) { eid_by_dst[k] = e; src_by_dst[k] = (int32_t)ei[e]; slot_of_eid[e] = (int32_t)k; }
-    else { eid_by_src[k - E] = e; dst_by_src[k - E] = (int32_t)ei[E + e]; }
-}
-
-__global__ void k_slot_map(const int32_t* __restrict__ eid_by_src, const int32_t* __restrict__ slot_of_eid, int64_t E,
-                           int32_t* __restrict__ slot_dst_of_srcslot) {
-    int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (k < E) slot_dst_of_srcslot[k] = slot_of_eid[eid_by_src[k]];
+    if (k < E) { eid_by_dst[k] = e; src_by_dst[k] = (int32_t)ei[e]; return; }
+    const int64_t draw = ei[E + e];
+    const int32_t d = (int32_t)draw;
+    eid_by_src[k - E] = e;
+    dst_by_src[k - E] = d;
+    // slot of edge e in the by-destination CSR: row d holds its edge ids in ascending order in perm[rowptr_dst[d] .. rowptr_dst[d+1])
+    if (draw < 0 || draw >= num_nodes) { slot_dst_of_srcslot[k - E] = 0; return; }      // reported through err_flag[0] by k_make_pair_keys
+    int lo = rowptr_dst[d], hi = rowptr_dst[d + 1];
+    while (lo < hi) {
+        const int mid = (lo + hi) >> 1;
+        if (perm[mid] < e) lo = mid + 1; else hi = mid;
+    }
+    slot_dst_of_srcslot[k - E] = lo;
 }
 
 struct ChunkCount2 {     // ChunkCount over the rows of both CSRs laid end to end: [0, N] by-destination, [N+1, 2N+1] by-source
@@ -319,7 +335,6 @@ int gsat_build_csr_pair(const int64_t* edge_index, int64_t E, int64_t N, int32_t
     uint32_t* keys_out = ar.take<uint32_t>(2 * E);
     int32_t* ids = ar.take<int32_t>(2 * E);
     int32_t* perm = ar.take<int32_t>(2 * E);
-    int32_t* slot_of_eid = ar.take<int32_t>(E);
     int32_t* scan = ar.take<int32_t>(2 * N + 2);
     size_t tb = sort_temp_bytes<uint32_t>(2 * E), tc = chunk2_scan_temp_bytes(N);
     char* temp = ar.take<char>(tb);
@@ -332,9 +347,8 @@ int gsat_build_csr_pair(const int64_t* edge_index, int64_t E, int64_t N, int32_t
     GSAT_CHECK_HIP(rocprim::radix_sort_pairs(temp, tb, keys_in, keys_out, ids, perm, (size_t)(2 * E), 0, (unsigned)end_bit, stream));
     k_pair_rowptrs<<<ceil_div(2 * N + 2, B), B, 0, stream>>>(keys_out, E, N, rowptr_dst, rowptr_src);
     GSAT_LAUNCH_CHECK();
-    k_pair_gather<<<ceil_div(2 * E, B), B, 0, stream>>>(edge_index, perm, E, src_by_dst, eid_by_dst, dst_by_src, eid_by_src, slot_of_eid);
-    GSAT_LAUNCH_CHECK();
-    k_slot_map<<<ceil_div(E, B), B, 0, stream>>>(eid_by_src, slot_of_eid, E, slot_dst_of_srcslot);
+    k_pair_gather<<<ceil_div(2 * E, B), B, 0, stream>>>(edge_index, perm, E, N, rowptr_dst, src_by_dst, eid_by_dst, dst_by_src, eid_by_src,
+                                                        slot_dst_of_srcslot);
     GSAT_LAUNCH_CHECK();
     auto in = rocprim::make_transform_iterator(rocprim::make_counting_iterator<int>(0), ChunkCount2{rowptr_dst, rowptr_src, (int)N});
     GSAT_CHECK_HIP(rocprim::exclusive_scan(temp2, tc, in, scan, 0, (size_t)(2 * N + 2), rocprim::plus<int>(), stream));
@@ -374,15 +388,10 @@ int gsat_segment_ptr(const int64_t* seg_ids, int64_t n, int64_t num_seg, int32_t
 int gsat_segment_ptr32(const int64_t* seg_ids, int64_t n, int64_t num_seg, int32_t* ptr, int32_t* seg_ids32, int32_t* flags, void* stream_) {
     hipStream_t stream = (hipStream_t)stream_;
     GSAT_REQUIRE(n >= 0 && num_seg >= 0 && ptr && flags, GSAT_ERR_ARG, "gsat_segment_ptr32: bad argument");
-    GSAT_REQUIRE(n < (1ll << 31), GSAT_ERR_UNSUPPORTED, "gsat_segment_ptr32: >2^31 rows");
+    GSAT_REQUIRE(n < (1ll << 31) && num_seg < (1ll << 31), GSAT_ERR_UNSUPPORTED, "gsat_segment_ptr32: >2^31 rows");
+    GSAT_REQUIRE(n == 0 || (seg_ids && seg_ids32), GSAT_ERR_ARG, "gsat_segment_ptr32: null ids");
     const int B = 256;
-    GSAT_CHECK_HIP(hipMemsetAsync(flags, 0, sizeof(int32_t), stream));
-    if (n > 0) {
-        GSAT_REQUIRE(seg_ids && seg_ids32, GSAT_ERR_ARG, "gsat_segment_ptr32: null ids");
-        k_check_sorted_narrow<<<ceil_div(n, B), B, 0, stream>>>(seg_ids, n, num_seg, flags, seg_ids32);
-        GSAT_LAUNCH_CHECK();
-    }
-    k_lower_bounds<int64_t><<<ceil_div(num_seg + 1, B), B, 0, stream>>>(seg_ids, n, num_seg, ptr);
+    k_segments<<<ceil_div(std::max<int64_t>(n, num_seg + 1), B), B, 0, stream>>>(seg_ids, n, num_seg, flags, seg_ids32, ptr);
     GSAT_LAUNCH_CHECK();
     return GSAT_OK;
 }

@@ -205,7 +205,7 @@ class GraphSegments:
             num_graphs = int(batch.max().item()) + 1 if n > 0 else 0     # reference: batch.max()+1 (sync)
         self.G = int(num_graphs)
         self.node_ptr = torch.empty(self.G + 1, dtype=torch.int32, device=dev)
-        flags = torch.empty(1, dtype=torch.int32, device=dev)           # zeroed by the call
+        flags = index._err[3:4]                   # pre-zeroed status word of the batch index (only ever incremented)
         self.node_seg32 = _i32(n, dev)            # graph id of every node, int32 (written by the same pass that checks the order)
         call("gsat_segment_ptr32", ptr(self.batch), n, self.G, ptr(self.node_ptr), ptr(self.node_seg32), ptr(flags), stream())
         self._flags = flags

@@ -95,7 +95,7 @@ int gsat_reverse_edge_perm(const int64_t* edge_index, int64_t num_edges, int64_t
  */
 int gsat_segment_ptr(const int64_t* seg_ids, int64_t num_rows, int64_t num_segments, int32_t* ptr,
                      int32_t* flags, void* stream);
-/* same, and also writes the int32 copy seg_ids32[n] of the ids in the checking pass (one launch fewer per batch) */
+/* same in ONE launch, plus the int32 copy seg_ids32[n] of the ids; *flags is only incremented: the caller zeroes it */
 int gsat_segment_ptr32(const int64_t* seg_ids, int64_t n, int64_t num_segments, int32_t* ptr, int32_t* seg_ids32,
                        int32_t* flags, void* stream);
 
