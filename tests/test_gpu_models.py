@@ -336,3 +336,41 @@ def test_colsum_matches_torch(dev):
     for R, C in [(1, 4), (63, 128), (51639, 128), (1000, 1)]:
         x = torch.randn(R, C, generator=g)
         close(colsum(x.to(dev)), x.double().sum(0).float(), 1e-5)
+
+
+@pytest.mark.parametrize("backbone,edge", [("GIN", False), ("PNA", True)])
+def test_training_trajectory_matches_oracle(dev, backbone, edge):
+    """example/trainer.py:28-36 repeated: forward_pass, zero_grad, backward, Adam -- 25 steps on the real MUTAG topology (fixture),
+    same noise / keep-masks on both sides.  The HIP stack and the CPU oracle must follow the same loss trajectory (the notebook's
+    sanity band, SURVEY 8c: the loss goes down) within fp32 drift."""
+    import dp_gsat_amd as G
+    from dp_gsat_amd import synth
+    data = synth.mutag_batch(os.path.join(ROOT, "tests", "golden", "mutag128.npz"), num_graphs=64)
+    H, steps = 32, 25
+    cfg = dict(model_name=backbone, n_layers=2, hidden_size=H, dropout_p=0.0, use_edge_attr=False,
+               aggregators=["mean", "min", "max", "std"], scalers=False, deg=synth.in_degree_histogram(data))
+    oclf, oext, clf, ext = _mk_pair(G, backbone, cfg, 14, 0, H, edge, dev)
+    ogsat = om.GSAT(oclf, oext, om.Criterion(2, False), learn_edge_att=edge).train()
+    oopt = torch.optim.Adam(list(oclf.parameters()) + list(oext.parameters()), lr=1e-3, weight_decay=3e-6)
+    opt = torch.optim.Adam(list(clf.parameters()) + list(ext.parameters()), lr=1e-3, weight_decay=3e-6)
+    gsat = G.GSAT(clf, ext, G.Criterion(2, False), opt, learn_edge_att=edge).train()
+    M = data.edge_index.shape[1] if edge else data.x.shape[0]
+    C1 = 4 * H if edge else 2 * H
+    ones = [torch.ones(M, C1), torch.ones(M, H)]
+    ddev = data.to(dev)
+    g = torch.Generator().manual_seed(21)
+    ref_losses, got_losses = [], []
+    for step in range(steps):
+        u = torch.rand(M, 1, generator=g).clamp_(1e-10, 1 - 1e-10)
+        _, ol, old, _, _ = ogsat.forward_pass(data, step, True, u=u, masks=ones)
+        oopt.zero_grad(); ol.backward(); oopt.step()
+        _, l, ld, _ = gsat.forward_pass(ddev, step, True, noise=u.to(dev), dropout_masks=[m.to(dev) for m in ones])
+        opt.zero_grad(); l.backward(); opt.step()
+        ref_losses.append(old["loss"]); got_losses.append(ld["loss"])
+    for i, (a, b) in enumerate(zip(got_losses, ref_losses)):
+        assert abs(a - b) <= 2e-2 * max(1.0, abs(b)), (i, a, b)
+    assert got_losses[-1] < 0.9 * got_losses[0], got_losses          # it learns
+    for (k, p), (_, q) in zip(list(clf.named_parameters()) + list(ext.named_parameters()),
+                              list(oclf.named_parameters()) + list(oext.named_parameters())):
+        assert torch.isfinite(p).all(), k
+        assert float((p.detach().cpu() - q.detach()).abs().max()) <= 5e-2 * max(1.0, float(q.detach().abs().max())), k
