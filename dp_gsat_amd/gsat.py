@@ -138,11 +138,14 @@ class GSAT(nn.Module):
         self.decay_r = decay_r
         self.sync_loss_dict = True       # the reference calls .item() three times per step (example/gsat.py:34)
 
-    def __loss__(self, att, clf_logits, clf_labels, epoch):
+    def __loss__(self, att, clf_logits, clf_labels, epoch, loss_weights=None):
         pred_loss = self.criterion(clf_logits, clf_labels)
         r = self.get_r(self.decay_interval, self.decay_r, epoch, final_r=self.final_r)
         i_loss = info_loss(att, r)
-        loss = pred_loss + i_loss
+        if loss_weights is None:
+            loss = pred_loss + i_loss
+        else:       # data-parallel shards: dist.global_loss_weights() makes the averaged gradients those of the global batch
+            loss = pred_loss * loss_weights[0] + i_loss * loss_weights[1]
         if self.sync_loss_dict:
             vals = torch.stack([loss.detach(), pred_loss.detach(), i_loss.detach()]).tolist()   # one sync, not three
             loss_dict = {"loss": vals[0], "pred": vals[1], "info": vals[2]}
@@ -150,9 +153,10 @@ class GSAT(nn.Module):
             loss_dict = {"loss": loss.detach(), "pred": pred_loss.detach(), "info": i_loss.detach()}
         return loss, loss_dict
 
-    def forward_pass(self, data, epoch, training, noise=None, dropout_masks=None):
+    def forward_pass(self, data, epoch, training, noise=None, dropout_masks=None, loss_weights=None):
         """Returns (edge_att, loss, loss_dict, clf_logits) like the reference.  ``noise`` / ``dropout_masks``
-        optionally pin the randomness (same-seed parity is impossible against torch's CPU generator)."""
+        optionally pin the randomness (same-seed parity is impossible against torch's CPU generator); ``loss_weights``
+        = (graph weight, attention-row weight) of a data-parallel shard (dp_gsat_amd.dist.global_loss_weights)."""
         N = data.x.shape[0]
         num_graphs = getattr(data, "num_graphs", None)
         if num_graphs is not None:      # PyG batches know their graph count: prime the segment cache without `batch.max()` (a sync)
@@ -167,7 +171,7 @@ class GSAT(nn.Module):
         else:
             edge_att = self.lift_node_att_to_edge_att(att, data.edge_index)
         clf_logits = self.clf(data.x, data.edge_index, data.batch, edge_attr=data.edge_attr, edge_atten=edge_att)
-        loss, loss_dict = self.__loss__(att, clf_logits, data.y, epoch)
+        loss, loss_dict = self.__loss__(att, clf_logits, data.y, epoch, loss_weights)
         return edge_att, loss, loss_dict, clf_logits
 
     @staticmethod
