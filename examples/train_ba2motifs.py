@@ -60,6 +60,7 @@ def main():
     ap.add_argument("--hidden", type=int, default=64)
     ap.add_argument("--backbone", default="GIN", choices=["GIN", "PNA"])
     ap.add_argument("--seed", type=int, default=0)
+    ap.add_argument("--backend", default="nccl", help="nccl (= RCCL, one GPU per rank) or gloo (to rehearse N ranks on one GPU)")
     args = ap.parse_args()
 
     world, rank = int(os.environ.get("WORLD_SIZE", "1")), int(os.environ.get("RANK", "0"))
@@ -67,7 +68,10 @@ def main():
     torch.cuda.set_device(dev)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        else:
+            dist.init_process_group(args.backend, rank=rank, world_size=world)
     import dp_gsat_amd as G
     from dp_gsat_amd.dist import FlatGradAllReduce, global_loss_weights, shard_graphs_lpt
     from sklearn.metrics import roc_auc_score
