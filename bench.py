@@ -278,6 +278,16 @@ def aggregation_roofline(wl, data, dev, reps=30, rounds=5):
 # ------------------------------------------------------------------------------------------------
 # CPU baseline: the oracle (plain-PyTorch restatement of the reference op sequence) on the host cores
 # ------------------------------------------------------------------------------------------------
+def _cpu_model():
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
 def cpu_baseline(wl, name, seed, sample_graphs, steps=5):
     from oracle import bookkeeping as bk
     from oracle import modules as om
@@ -338,7 +348,7 @@ def cpu_baseline(wl, name, seed, sample_graphs, steps=5):
     return dict(value=round(E / t / 1e6, 5), unit="million edges/s", cores=int(threads), kind="port",
                 sample=f"oracle scope-A step on the first {sample_graphs} of {full.num_graphs} graphs of the workload "
                        f"({N} nodes, {E} directed edges), 1 warm-up + median of {steps} steps, {t * 1e3:.1f} ms/step",
-                by_threads={str(k): round(E / v / 1e6, 5) for k, v in results.items()}, host_cpus=os.cpu_count())
+                by_threads={str(k): round(E / v / 1e6, 5) for k, v in results.items()}, host_cpus=os.cpu_count(), cpu_model=_cpu_model())
 
 
 def main():
