@@ -140,13 +140,15 @@ __global__ __launch_bounds__(PNA_BLOCK) void k_pna_fwd(
         if (!on) continue;
         const Acc4 ai = self_stats(xi, sa, sa2, amin, amax);
         float* orow = out + (size_t)row * out_stride;
-        if (NAGG) {        // (mean, min, max, std[, sum]; identity), no edge part: 2 * NAGG fixed segments
+        if (NAGG) {        // (mean, min, max, std[, sum]; identity): NAGG * parts fixed segments, order [aggregator][part]
             float* o = orow + c;
-            st4_nt(o, agg_value4(AGG_MEAN, ai, cnt));           st4_nt(o + H, agg_value4(AGG_MEAN, aj, cnt));
-            st4_nt(o + 2 * H, agg_value4(AGG_MIN, ai, cnt));    st4_nt(o + 3 * H, agg_value4(AGG_MIN, aj, cnt));
-            st4_nt(o + 4 * H, agg_value4(AGG_MAX, ai, cnt));    st4_nt(o + 5 * H, agg_value4(AGG_MAX, aj, cnt));
-            st4_nt(o + 6 * H, agg_value4(GSAT_AGG_STD, ai, cnt)); st4_nt(o + 7 * H, agg_value4(GSAT_AGG_STD, aj, cnt));
-            if (NAGG == 5) { st4_nt(o + 8 * H, ai.s); st4_nt(o + 9 * H, aj.s); }
+            constexpr int kAgg[5] = {AGG_MEAN, AGG_MIN, AGG_MAX, GSAT_AGG_STD, AGG_SUM};
+#pragma unroll
+            for (int a = 0; a < NAGG; ++a) {
+                st4_nt(o + (size_t)(a * parts) * H, agg_value4(kAgg[a], ai, cnt));
+                st4_nt(o + (size_t)(a * parts + 1) * H, agg_value4(kAgg[a], aj, cnt));
+                if (HAS_EE) st4_nt(o + (size_t)(a * parts + 2) * H, agg_value4(kAgg[a], ae, cnt));
+            }
             continue;
         }
         for (int s = 0; s < cfg.S; ++s) {
@@ -172,7 +174,7 @@ __global__ __launch_bounds__(PNA_BLOCK, HAS_EE ? 2 : 4) void k_pna_bwd_dst(
     constexpr int GPB = PNA_BLOCK / LPR;
     // The upstream gradient row (S*A*parts segments of H floats, 64 % of the kernel's bytes) is fetched by LDS-DMA at
     // the top of the row, so its HBM latency overlaps the index -> att -> x_j dependency chain without holding VGPRs.
-    constexpr int MAXSEG = NAGG == 5 ? 10 : 8;
+    constexpr int MAXSEG = NAGG ? NAGG * (HAS_EE ? 3 : 2) : 8;
     __shared__ float4 stage[MAXSEG][PNA_BLOCK];
     const int lane = threadIdx.x % LPR;
     const int c = lane * 4;
@@ -443,15 +445,15 @@ int gsat_pna_fwd(const float* x, const float* att, const float* edge_emb, const 
     int nb, rpg;
     pna_grid(N, lpr, &nb, &rpg);
     const int nagg = fixed_aggregators(cfg);
+#define GO(L, EE, NA) k_pna_fwd<L, EE, NA><<<nb, PNA_BLOCK, 0, stream>>>(x, att, edge_emb, rowptr, col, eid, (int)N, (int)H, cfg, out, rpg)
 #define CALL(L)                                                                                                              \
     do {                                                                                                                     \
-        if (edge_emb) k_pna_fwd<L, true, 0><<<nb, PNA_BLOCK, 0, stream>>>(x, att, edge_emb, rowptr, col, eid, (int)N, (int)H, cfg, out, rpg); \
-        else if (nagg == 4) k_pna_fwd<L, false, 4><<<nb, PNA_BLOCK, 0, stream>>>(x, att, edge_emb, rowptr, col, eid, (int)N, (int)H, cfg, out, rpg); \
-        else if (nagg == 5) k_pna_fwd<L, false, 5><<<nb, PNA_BLOCK, 0, stream>>>(x, att, edge_emb, rowptr, col, eid, (int)N, (int)H, cfg, out, rpg); \
-        else k_pna_fwd<L, false, 0><<<nb, PNA_BLOCK, 0, stream>>>(x, att, edge_emb, rowptr, col, eid, (int)N, (int)H, cfg, out, rpg);         \
+        if (edge_emb) { if (nagg == 4) GO(L, true, 4); else if (nagg == 5) GO(L, true, 5); else GO(L, true, 0); }            \
+        else { if (nagg == 4) GO(L, false, 4); else if (nagg == 5) GO(L, false, 5); else GO(L, false, 0); }                  \
     } while (0)
     GSAT_LPR_DISPATCH(lpr, CALL);
 #undef CALL
+#undef GO
     GSAT_LAUNCH_CHECK();
     return GSAT_OK;
 }
@@ -472,15 +474,15 @@ int gsat_pna_bwd(const float* x, const float* att, const float* edge_emb, const 
     int nb, rpg;
     pna_grid(N, lpr, &nb, &rpg);
     const int nagg = fixed_aggregators(cfg);
+#define GO(L, EE, NA) k_pna_bwd_dst<L, EE, NA><<<nb, PNA_BLOCK, 0, stream>>>(x, att, edge_emb, dout, rowptr, col, eid, (int)N, (int)H, cfg, dx_self, dmsg, datt, dedge_emb, rpg)
 #define CALL(L)                                                                                                              \
     do {                                                                                                                     \
-        if (edge_emb) k_pna_bwd_dst<L, true, 0><<<nb, PNA_BLOCK, 0, stream>>>(x, att, edge_emb, dout, rowptr, col, eid, (int)N, (int)H, cfg, dx_self, dmsg, datt, dedge_emb, rpg); \
-        else if (nagg == 4) k_pna_bwd_dst<L, false, 4><<<nb, PNA_BLOCK, 0, stream>>>(x, att, edge_emb, dout, rowptr, col, eid, (int)N, (int)H, cfg, dx_self, dmsg, datt, dedge_emb, rpg); \
-        else if (nagg == 5) k_pna_bwd_dst<L, false, 5><<<nb, PNA_BLOCK, 0, stream>>>(x, att, edge_emb, dout, rowptr, col, eid, (int)N, (int)H, cfg, dx_self, dmsg, datt, dedge_emb, rpg); \
-        else k_pna_bwd_dst<L, false, 0><<<nb, PNA_BLOCK, 0, stream>>>(x, att, edge_emb, dout, rowptr, col, eid, (int)N, (int)H, cfg, dx_self, dmsg, datt, dedge_emb, rpg);         \
+        if (edge_emb) { if (nagg == 4) GO(L, true, 4); else if (nagg == 5) GO(L, true, 5); else GO(L, true, 0); }            \
+        else { if (nagg == 4) GO(L, false, 4); else if (nagg == 5) GO(L, false, 5); else GO(L, false, 0); }                  \
     } while (0)
     GSAT_LPR_DISPATCH(lpr, CALL);
 #undef CALL
+#undef GO
     GSAT_LAUNCH_CHECK();
     return GSAT_OK;
 }

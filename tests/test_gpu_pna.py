@@ -52,25 +52,36 @@ def test_pna_fwd_bwd(dev, H, aggr, scalers, masked):
         close(ad.grad, r32[2], ref64=r64[2], what="datt")
 
 
-def test_pna_with_edge_attr(dev):
+@pytest.mark.parametrize("H", [32, 80, 128])
+@pytest.mark.parametrize("aggr", [["mean", "min", "max", "std"], ["mean", "min", "max", "std", "sum"], ["max", "var", "mean"]])
+def test_pna_with_edge_attr(dev, H, aggr):
+    """message = att * [x_i || x_j || edge_emb] (PNA on spmotif / mnist: edge_attr present, src/models/conv_layers.py:168-171); the
+    first two aggregator lists take the compile-time instantiations, the third the generic kernel."""
     from dp_gsat_amd.graph_index import BatchIndex
     from dp_gsat_amd.ops import pna_aggregate
-    H = 32
-    ei, batch, N = random_batch(5, 6, 2, 25)
+    ei, batch, N = random_batch(5 + H, 6, 2, 25)
     E = ei.shape[1]
     g = torch.Generator().manual_seed(9)
     x, ee, att = torch.randn(N, H, generator=g), torch.randn(E, H, generator=g), torch.rand(E, 1, generator=g)
-    aggr, scalers = ["mean", "min", "max", "std"], ["identity"]
+    x[::4] = x[::4].relu()
+    scalers = ["identity"]
     avg = oops.pna_avg_deg(torch.from_numpy(obk.deg_histogram(ei, N)))
-    go = torch.randn(N, 4 * 3 * H, generator=g)
-    xo, eo, ao = (t.clone().requires_grad_(True) for t in (x, ee, att))
-    oo = oops.pna_aggregate(xo, ei, ao, aggr, scalers, avg, eo)
-    oo.backward(go)
+    go = torch.randn(N, len(aggr) * 3 * H, generator=g)
+    ref = {}
+    for dt in (torch.float32, torch.float64):
+        xo, eo, ao = (t.to(dt).clone().requires_grad_(True) for t in (x, ee, att))
+        oo = oops.pna_aggregate(xo, ei, ao, aggr, scalers, avg, eo)
+        oo.backward(go.to(dt))
+        ref[dt] = (oo, xo.grad, eo.grad, ao.grad)
     ix = BatchIndex(ei.to(dev), N)
     xd, ed, ad = (t.to(dev).requires_grad_(True) for t in (x, ee, att))
     od = pna_aggregate(xd, ix, ad, ed, aggr, scalers, avg)
     od.backward(go.to(dev))
-    close(od, oo); close(xd.grad, xo.grad, 2e-4); close(ed.grad, eo.grad, 2e-4); close(ad.grad, ao.grad, 2e-4)
+    r32, r64 = ref[torch.float32], ref[torch.float64]
+    close(od, r32[0], ref64=r64[0], what="out")
+    close(xd.grad, r32[1], 2e-4, ref64=r64[1], what="dx")
+    close(ed.grad, r32[2], 2e-4, ref64=r64[2], what="dedge")
+    close(ad.grad, r32[3], 2e-4, ref64=r64[3], what="datt")
 
 
 def test_pna_empty_rows_std(dev):
