@@ -127,10 +127,15 @@ __global__ void k_zcombine(const float* __restrict__ part, const int32_t* __rest
 // per-graph, per-channel InstanceNorm statistics: grid (G, ceil(C/64)); two passes over the segment
 // (mean, then variance of the centred values -- the reference's order), second pass is L2-hot.
 // ------------------------------------------------------------------------------------------------
-template <bool EDGE>
+// APPLY: a third pass over the (now cache-hot) rows of the segment writes the layer's activation
+//   a[m,c] = relu((h - mean) * rstd) * keep / (1-p)
+// so the layer needs no separate normalise kernel (k_norm_apply) and no second trip of h through HBM.
+template <bool EDGE, bool APPLY>
 __global__ __launch_bounds__(SB) void k_seg_stats(PreAct<EDGE> pre, const int32_t* __restrict__ seg_ptr,
                                                   const int32_t* __restrict__ order, float* __restrict__ mean_out,
-                                                  float* __restrict__ rstd_out) {
+                                                  float* __restrict__ rstd_out, const float* __restrict__ mask = nullptr,
+                                                  SeedRef seed = SeedRef{0, nullptr}, int layer = 0, float p = 0.f, int training = 0,
+                                                  float* __restrict__ act_out = nullptr) {
     __shared__ float4 sm[SB_SLOTS][SB_LANES];
     __shared__ float4 bc[SB_LANES];
     const int g = blockIdx.x;
@@ -158,11 +163,26 @@ __global__ __launch_bounds__(SB) void k_seg_stats(PreAct<EDGE> pre, const int32_
             acc.x = fmaf(dx, dx, acc.x); acc.y = fmaf(dy, dy, acc.y); acc.z = fmaf(dz, dz, acc.z); acc.w = fmaf(dw, dw, acc.w);
         }
     tot = slot_reduce(acc, sm, slot, lane);
+    float4 rs = make_float4(1.f / sqrtf(tot.x * inv_n + IN_EPS), 1.f / sqrtf(tot.y * inv_n + IN_EPS),
+                            1.f / sqrtf(tot.z * inv_n + IN_EPS), 1.f / sqrtf(tot.w * inv_n + IN_EPS));
     if (slot == 0 && on) {
         st4(mean_out + (size_t)g * C + c, mu);
-        st4(rstd_out + (size_t)g * C + c,
-            make_float4(1.f / sqrtf(tot.x * inv_n + IN_EPS), 1.f / sqrtf(tot.y * inv_n + IN_EPS),
-                        1.f / sqrtf(tot.z * inv_n + IN_EPS), 1.f / sqrtf(tot.w * inv_n + IN_EPS)));
+        st4(rstd_out + (size_t)g * C + c, rs);
+    }
+    if (APPLY) {
+        if (slot == 0) bc[lane] = rs;              // every thread took `mu` out of bc before slot_reduce's barriers
+        __syncthreads();
+        rs = bc[lane];
+        const float sc = (training && p > 0.f) ? 1.f / (1.f - p) : 1.f;
+        if (on)
+            for (int r = beg + slot; r < end; r += SB_SLOTS) {
+                const int m = order ? order[r] : r;
+                const float4 h = pre.load(m, c);
+                const float4 k = keep4(mask, seed, layer, m, c, C, p, training != 0);
+                st4(act_out + (size_t)m * C + c,
+                    make_float4(fmaxf((h.x - mu.x) * rs.x, 0.f) * k.x * sc, fmaxf((h.y - mu.y) * rs.y, 0.f) * k.y * sc,
+                                fmaxf((h.z - mu.z) * rs.z, 0.f) * k.z * sc, fmaxf((h.w - mu.w) * rs.w, 0.f) * k.w * sc));
+            }
     }
 }
 
@@ -478,7 +498,7 @@ static int launch_seg_stats(hipStream_t stream, PreAct<EDGE> pre, const int32_t*
     const int C = pre.C;
     const dim3 grid((unsigned)G, (unsigned)ceil_div(C, 64), (unsigned)Z);
     if (Z == 1) {
-        k_seg_stats<EDGE><<<grid, SB, 0, stream>>>(pre, seg_ptr, order, mean, rstd);
+        k_seg_stats<EDGE, false><<<grid, SB, 0, stream>>>(pre, seg_ptr, order, mean, rstd);
     } else {
         GSAT_REQUIRE(part, GSAT_ERR_WORKSPACE, "segmented statistics need a workspace for sliced segments");
         const unsigned cb = (unsigned)ceil_div(G * C, 256);
@@ -552,14 +572,24 @@ int gsat_attn_fwd(const gsat_attn_args* a, void* stream_) {
         GSAT_REQUIRE(a->fwd_workspace && a->fwd_workspace_bytes >= need, GSAT_ERR_WORKSPACE, "gsat_attn_fwd: workspace %zu < %zu", a->fwd_workspace_bytes, need);
         part = static_cast<float*>(a->fwd_workspace);
     }
+    const dim3 sgrid((unsigned)G, (unsigned)ceil_div(C1, 64), 1);
+    const SeedRef sref{a->seed, a->seed_dev};
     if (a->edge_mode) {
         PreAct<true> pre{a->P, a->Q, a->b1, a->src, a->dst, C1};
-        if ((rc = launch_seg_stats<true>(stream, pre, a->seg_ptr, a->seg_order, G, Z, mean1, rstd1, part))) return rc;
-        k_norm_apply<true, true><<<ew_blocks(M * (C1 / 4)), 256, 0, stream>>>(pre, a->row_seg, mean1, rstd1, a->mask1, SeedRef{a->seed, a->seed_dev}, 1, a->p_drop, a->training, M, a->a1);
+        if (Z == 1 && G > 0) {        // statistics and activation in one launch: the rows of the segment are re-read from cache
+            k_seg_stats<true, true><<<sgrid, SB, 0, stream>>>(pre, a->seg_ptr, a->seg_order, mean1, rstd1, a->mask1, sref, 1, a->p_drop, a->training, a->a1);
+        } else {
+            if ((rc = launch_seg_stats<true>(stream, pre, a->seg_ptr, a->seg_order, G, Z, mean1, rstd1, part))) return rc;
+            k_norm_apply<true, true><<<ew_blocks(M * (C1 / 4)), 256, 0, stream>>>(pre, a->row_seg, mean1, rstd1, a->mask1, sref, 1, a->p_drop, a->training, M, a->a1);
+        }
     } else {
         PreAct<false> pre{a->P, nullptr, a->b1, nullptr, nullptr, C1};
-        if ((rc = launch_seg_stats<false>(stream, pre, a->seg_ptr, a->seg_order, G, Z, mean1, rstd1, part))) return rc;
-        k_norm_apply<false, true><<<ew_blocks(M * (C1 / 4)), 256, 0, stream>>>(pre, a->row_seg, mean1, rstd1, a->mask1, SeedRef{a->seed, a->seed_dev}, 1, a->p_drop, a->training, M, a->a1);
+        if (Z == 1 && G > 0) {
+            k_seg_stats<false, true><<<sgrid, SB, 0, stream>>>(pre, a->seg_ptr, a->seg_order, mean1, rstd1, a->mask1, sref, 1, a->p_drop, a->training, a->a1);
+        } else {
+            if ((rc = launch_seg_stats<false>(stream, pre, a->seg_ptr, a->seg_order, G, Z, mean1, rstd1, part))) return rc;
+            k_norm_apply<false, true><<<ew_blocks(M * (C1 / 4)), 256, 0, stream>>>(pre, a->row_seg, mean1, rstd1, a->mask1, sref, 1, a->p_drop, a->training, M, a->a1);
+        }
     }
     GSAT_LAUNCH_CHECK();
     // ---- layer 2 ----------------------------------------------------------------------------
@@ -719,7 +749,7 @@ int gsat_instance_norm_fwd(const float* x, const int32_t* seg_ptr, const int32_t
     float* mean = stats;
     float* rstd = stats + (size_t)G * C;
     PreAct<false> pre{x, nullptr, nullptr, nullptr, nullptr, (int)C};
-    k_seg_stats<false><<<dim3((unsigned)G, (unsigned)ceil_div(C, 64), 1), SB, 0, stream>>>(pre, seg_ptr, seg_order, mean, rstd);
+    k_seg_stats<false, false><<<dim3((unsigned)G, (unsigned)ceil_div(C, 64), 1), SB, 0, stream>>>(pre, seg_ptr, seg_order, mean, rstd);
     k_norm_apply<false, false><<<ew_blocks(M * (C / 4)), 256, 0, stream>>>(pre, row_seg, mean, rstd, nullptr, SeedRef{0, nullptr}, 0, 0.f, 0, M, y);
     GSAT_LAUNCH_CHECK();
     return GSAT_OK;
