@@ -259,13 +259,17 @@ __global__ void k_dz(const float* __restrict__ dlogits, const float* __restrict_
 
 // Backward statistics of layer 2 (through the head): per (graph, channel)
 //   S1 = mean_r dy2 , S2 = mean_r dy2*yhat2 , dw3 partial = sum_r dz * a2
+// APPLY (unsliced segments only): a second pass over the cache-hot rows writes dh2 = rstd2 * (dy2 - S1 - yhat2 * S2), i.e. k_dh2
+template <bool APPLY>
 __global__ __launch_bounds__(SB) void k_head_bwd_stats(const float* __restrict__ h2, const float* __restrict__ b2,
                                                        const int32_t* __restrict__ seg_ptr, const int32_t* __restrict__ order,
                                                        const float* __restrict__ mean, const float* __restrict__ rstd,
                                                        const float* __restrict__ mask, SeedRef seed, float p, int training,
                                                        const float* __restrict__ w3, const float* __restrict__ dz, int C,
-                                                       float* __restrict__ S1, float* __restrict__ S2, float* __restrict__ dw3p) {
+                                                       float* __restrict__ S1, float* __restrict__ S2, float* __restrict__ dw3p,
+                                                       float* __restrict__ dh2 = nullptr) {
     __shared__ float4 sm[SB_SLOTS][SB_LANES];
+    __shared__ float4 bc1[SB_LANES], bc2[SB_LANES];
     const int g = blockIdx.x;
     const int lane = threadIdx.x % SB_LANES, slot = threadIdx.x / SB_LANES;
     const int c = (blockIdx.y * SB_LANES + lane) * 4;
@@ -296,10 +300,30 @@ __global__ __launch_bounds__(SB) void k_head_bwd_stats(const float* __restrict__
     float4 t1 = slot_reduce(a1, sm, slot, lane);
     float4 t2 = slot_reduce(a2, sm, slot, lane);
     float4 t3 = slot_reduce(a3, sm, slot, lane);
+    t1 = make_float4(t1.x * inv_n, t1.y * inv_n, t1.z * inv_n, t1.w * inv_n);
+    t2 = make_float4(t2.x * inv_n, t2.y * inv_n, t2.z * inv_n, t2.w * inv_n);
     if (slot == 0 && on) {
-        st4(S1 + orow * C + c, make_float4(t1.x * inv_n, t1.y * inv_n, t1.z * inv_n, t1.w * inv_n));
-        st4(S2 + orow * C + c, make_float4(t2.x * inv_n, t2.y * inv_n, t2.z * inv_n, t2.w * inv_n));
+        st4(S1 + orow * C + c, t1);
+        st4(S2 + orow * C + c, t2);
         st4(dw3p + orow * C + c, t3);
+    }
+    if (APPLY) {
+        if (slot == 0) { bc1[lane] = t1; bc2[lane] = t2; }
+        __syncthreads();
+        if (!on) return;
+        const float4 s1 = bc1[lane], s2 = bc2[lane];
+        const float4 mu = ld4(mean + (size_t)g * C + c), rs = ld4(rstd + (size_t)g * C + c), w = ld4(w3 + c);
+        for (int r = beg + slot; r < end; r += SB_SLOTS) {
+            const int m = order ? order[r] : r;
+            const float d = dz[m];
+            const float4 h = pre.load(m, c);
+            const float4 k = keep4(mask, seed, 2, m, c, C, p, training != 0);
+            const float4 y = make_float4((h.x - mu.x) * rs.x, (h.y - mu.y) * rs.y, (h.z - mu.z) * rs.z, (h.w - mu.w) * rs.w);
+            const float4 dy = make_float4(y.x > 0.f ? d * w.x * k.x * sc : 0.f, y.y > 0.f ? d * w.y * k.y * sc : 0.f,
+                                          y.z > 0.f ? d * w.z * k.z * sc : 0.f, y.w > 0.f ? d * w.w * k.w * sc : 0.f);
+            st4(dh2 + (size_t)m * C + c, make_float4(rs.x * (dy.x - s1.x - y.x * s2.x), rs.y * (dy.y - s1.y - y.y * s2.y),
+                                                      rs.z * (dy.z - s1.z - y.z * s2.z), rs.w * (dy.w - s1.w - y.w * s2.w)));
+        }
     }
 }
 
@@ -328,10 +352,15 @@ __global__ void k_dh2(const float* __restrict__ h2, const float* __restrict__ b2
 }
 
 // Backward statistics of layer 1 from (da1, a1):  dy1 = da1*[a1>0]*sc ; yhat1*[a1>0] = a1/sc
-__global__ __launch_bounds__(SB) void k_l1_bwd_stats(const float* __restrict__ da1, const float* __restrict__ a1,
+// APPLY (unsliced segments only): a second pass writes dh1 in place over da1, i.e. k_dh1
+template <bool APPLY, bool EDGE>
+__global__ __launch_bounds__(SB) void k_l1_bwd_stats(float* __restrict__ da1, const float* __restrict__ a1,
                                                      const int32_t* __restrict__ seg_ptr, const int32_t* __restrict__ order,
-                                                     float sc, int C, float* __restrict__ S1, float* __restrict__ S2) {
+                                                     float sc, int C, float* __restrict__ S1, float* __restrict__ S2,
+                                                     PreAct<EDGE> pre = PreAct<EDGE>{}, const float* __restrict__ mean = nullptr,
+                                                     const float* __restrict__ rstd = nullptr) {
     __shared__ float4 sm[SB_SLOTS][SB_LANES];
+    __shared__ float4 bc1[SB_LANES], bc2[SB_LANES];
     const int g = blockIdx.x;
     const int lane = threadIdx.x % SB_LANES, slot = threadIdx.x / SB_LANES;
     const int c = (blockIdx.y * SB_LANES + lane) * 4;
@@ -353,9 +382,27 @@ __global__ __launch_bounds__(SB) void k_l1_bwd_stats(const float* __restrict__ d
         }
     float4 t1 = slot_reduce(s1, sm, slot, lane);
     float4 t2 = slot_reduce(s2, sm, slot, lane);
+    t1 = make_float4(t1.x * inv_n, t1.y * inv_n, t1.z * inv_n, t1.w * inv_n);
+    t2 = make_float4(t2.x * inv_n, t2.y * inv_n, t2.z * inv_n, t2.w * inv_n);
     if (slot == 0 && on) {
-        st4(S1 + orow * C + c, make_float4(t1.x * inv_n, t1.y * inv_n, t1.z * inv_n, t1.w * inv_n));
-        st4(S2 + orow * C + c, make_float4(t2.x * inv_n, t2.y * inv_n, t2.z * inv_n, t2.w * inv_n));
+        st4(S1 + orow * C + c, t1);
+        st4(S2 + orow * C + c, t2);
+    }
+    if (APPLY) {
+        if (slot == 0) { bc1[lane] = t1; bc2[lane] = t2; }
+        __syncthreads();
+        if (!on) return;
+        const float4 q1 = bc1[lane], q2 = bc2[lane];
+        const float4 mu = ld4(mean + (size_t)g * C + c), rs = ld4(rstd + (size_t)g * C + c);
+        for (int r = beg + slot; r < end; r += SB_SLOTS) {
+            const int m = order ? order[r] : r;
+            const float4 h = pre.load(m, c);
+            const float4 y = make_float4((h.x - mu.x) * rs.x, (h.y - mu.y) * rs.y, (h.z - mu.z) * rs.z, (h.w - mu.w) * rs.w);
+            const float4 d = ld4(da1 + (size_t)m * C + c), a = ld4(a1 + (size_t)m * C + c);
+            const float4 dy = make_float4(a.x > 0.f ? d.x * sc : 0.f, a.y > 0.f ? d.y * sc : 0.f, a.z > 0.f ? d.z * sc : 0.f, a.w > 0.f ? d.w * sc : 0.f);
+            st4(da1 + (size_t)m * C + c, make_float4(rs.x * (dy.x - q1.x - y.x * q2.x), rs.y * (dy.y - q1.y - y.y * q2.y),
+                                                      rs.z * (dy.z - q1.z - y.z * q2.z), rs.w * (dy.w - q1.w - y.w * q2.w)));
+        }
     }
 }
 
@@ -692,8 +739,12 @@ int gsat_attn_bwd(const gsat_attn_args* a, const gsat_attn_grads* gr, void* stre
     if ((rc = colsum(stream, dz, M, 1, gr->db3, scratch))) return rc;
     // ---- through the head and the second InstanceNorm ------------------------------------------
     const dim3 g2((unsigned)G, (unsigned)ceil_div(C2, 64), (unsigned)Z), g1((unsigned)G, (unsigned)ceil_div(C1, 64), (unsigned)Z);
-    k_head_bwd_stats<<<g2, SB, 0, stream>>>(a->h2, a->b2, a->seg_ptr, a->seg_order, mean2, rstd2, a->mask2, SeedRef{a->seed, a->seed_dev}, a->p_drop,
-                                            a->training, a->W3, dz, C2, Z > 1 ? zp1 : S1, Z > 1 ? zp2 : S2, Z > 1 ? zp3 : dw3p);
+    if (Z == 1)          // statistics and dh2 in one launch
+        k_head_bwd_stats<true><<<g2, SB, 0, stream>>>(a->h2, a->b2, a->seg_ptr, a->seg_order, mean2, rstd2, a->mask2, SeedRef{a->seed, a->seed_dev}, a->p_drop,
+                                                      a->training, a->W3, dz, C2, S1, S2, dw3p, dh2);
+    else
+        k_head_bwd_stats<false><<<g2, SB, 0, stream>>>(a->h2, a->b2, a->seg_ptr, a->seg_order, mean2, rstd2, a->mask2, SeedRef{a->seed, a->seed_dev}, a->p_drop,
+                                                       a->training, a->W3, dz, C2, zp1, zp2, zp3);
     if (Z > 1) {
         const unsigned cb = (unsigned)ceil_div(G * C2, 256);
         k_zcombine<<<cb, 256, 0, stream>>>(zp1, a->seg_ptr, (int)G, Z, C2, 1, S1);
@@ -702,14 +753,26 @@ int gsat_attn_bwd(const gsat_attn_args* a, const gsat_attn_grads* gr, void* stre
     }
     GSAT_LAUNCH_CHECK();
     if ((rc = colsum(stream, dw3p, G, C2, gr->dW3, scratch))) return rc;
-    k_dh2<<<ew_blocks(M * (C2 / 4)), 256, 0, stream>>>(a->h2, a->b2, a->row_seg, mean2, rstd2, a->mask2, SeedRef{a->seed, a->seed_dev}, a->p_drop, a->training,
-                                                       a->W3, dz, S1, S2, M, C2, dh2);
-    GSAT_LAUNCH_CHECK();
+    if (Z > 1) {
+        k_dh2<<<ew_blocks(M * (C2 / 4)), 256, 0, stream>>>(a->h2, a->b2, a->row_seg, mean2, rstd2, a->mask2, SeedRef{a->seed, a->seed_dev}, a->p_drop, a->training,
+                                                           a->W3, dz, S1, S2, M, C2, dh2);
+        GSAT_LAUNCH_CHECK();
+    }
     // dW2[C2,C1] = dh2^T a1 ; da1[M,C1] = dh2 W2
     if ((rc = gemm_rm(stream, true, false, C2, C1, M, dh2, C2, a->a1, C1, 0.f, gr->dW2, C1, gws))) return rc;
     if ((rc = gemm_rm(stream, false, false, M, C1, C2, dh2, C2, a->W2, C1, 0.f, da1, C1))) return rc;
     // ---- through ReLU/dropout and the first InstanceNorm ---------------------------------------
-    k_l1_bwd_stats<<<g1, SB, 0, stream>>>(da1, a->a1, a->seg_ptr, a->seg_order, sc, C1, Z > 1 ? zp1 : S1p, Z > 1 ? zp2 : S2p);
+    if (Z == 1) {        // statistics and dh1 (in place over da1) in one launch
+        if (a->edge_mode) {
+            PreAct<true> pre1{a->P, a->Q, a->b1, a->src, a->dst, C1};
+            k_l1_bwd_stats<true, true><<<g1, SB, 0, stream>>>(da1, a->a1, a->seg_ptr, a->seg_order, sc, C1, S1p, S2p, pre1, mean1, rstd1);
+        } else {
+            PreAct<false> pre1{a->P, nullptr, a->b1, nullptr, nullptr, C1};
+            k_l1_bwd_stats<true, false><<<g1, SB, 0, stream>>>(da1, a->a1, a->seg_ptr, a->seg_order, sc, C1, S1p, S2p, pre1, mean1, rstd1);
+        }
+    } else {
+        k_l1_bwd_stats<false, false><<<g1, SB, 0, stream>>>(da1, a->a1, a->seg_ptr, a->seg_order, sc, C1, zp1, zp2);
+    }
     if (Z > 1) {
         const unsigned cb = (unsigned)ceil_div(G * C1, 256);
         k_zcombine<<<cb, 256, 0, stream>>>(zp1, a->seg_ptr, (int)G, Z, C1, 1, S1p);
@@ -717,9 +780,11 @@ int gsat_attn_bwd(const gsat_attn_args* a, const gsat_attn_grads* gr, void* stre
     }
     GSAT_LAUNCH_CHECK();
     if (a->edge_mode) {
-        PreAct<true> pre{a->P, a->Q, a->b1, a->src, a->dst, C1};
-        k_dh1<true><<<ew_blocks(M * (C1 / 4)), 256, 0, stream>>>(pre, a->row_seg, mean1, rstd1, a->a1, sc, S1p, S2p, M, da1);
-        GSAT_LAUNCH_CHECK();
+        if (Z > 1) {
+            PreAct<true> pre{a->P, a->Q, a->b1, a->src, a->dst, C1};
+            k_dh1<true><<<ew_blocks(M * (C1 / 4)), 256, 0, stream>>>(pre, a->row_seg, mean1, rstd1, a->a1, sc, S1p, S2p, M, da1);
+            GSAT_LAUNCH_CHECK();
+        }
         // dP[n,:] = sum over out-edges of n of dh1[e,:], dQ[n,:] = sum over in-edges (gather-sum, hub rows chunked)
         if ((rc = aggr_sum_fwd_impl(stream, da1, nullptr, nullptr, nullptr, gr->rowptr_src, gr->eid_by_src, nullptr, N, M, C1, 0.f, dP,
                                     gr->chunk_ptr_src, lpart))) return rc;
@@ -731,9 +796,11 @@ int gsat_attn_bwd(const gsat_attn_args* a, const gsat_attn_grads* gr, void* stre
         if ((rc = gemm_rm(stream, true, false, C1, H, N, dP, C1, a->emb, H, 0.f, gr->dW1, 2 * H, gws))) return rc;
         if ((rc = gemm_rm(stream, true, false, C1, H, N, dQ, C1, a->emb, H, 0.f, gr->dW1 + H, 2 * H, gws))) return rc;
     } else {
-        PreAct<false> pre{a->P, nullptr, a->b1, nullptr, nullptr, C1};
-        k_dh1<false><<<ew_blocks(M * (C1 / 4)), 256, 0, stream>>>(pre, a->row_seg, mean1, rstd1, a->a1, sc, S1p, S2p, M, da1);
-        GSAT_LAUNCH_CHECK();
+        if (Z > 1) {
+            PreAct<false> pre{a->P, nullptr, a->b1, nullptr, nullptr, C1};
+            k_dh1<false><<<ew_blocks(M * (C1 / 4)), 256, 0, stream>>>(pre, a->row_seg, mean1, rstd1, a->a1, sc, S1p, S2p, M, da1);
+            GSAT_LAUNCH_CHECK();
+        }
         if ((rc = gemm_rm(stream, false, false, N, H, C1, da1, C1, a->W1, H, 0.f, gr->demb, H))) return rc;
         if ((rc = gemm_rm(stream, true, false, C1, H, N, da1, C1, a->emb, H, 0.f, gr->dW1, H, gws))) return rc;
     }
