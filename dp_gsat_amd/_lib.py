@@ -25,7 +25,7 @@ SIGNATURES = {
     "gsat_build_csr": (INT, [P, P, I64, I64, P, P, P, P, P, SZ, P]),
     "gsat_reverse_edge_perm": (INT, [P, I64, I64, P, P, P, SZ, P]),
     "gsat_segment_ptr": (INT, [P, I64, I64, P, P, P]),
-    "gsat_gather_i64": (INT, [P, P, I64, P, P]),
+    "gsat_gather_i64": (INT, [P, I64, P, I64, P, P]),
     "gsat_row_chunks_workspace_bytes": (SZ, [I64]),
     "gsat_row_chunks": (INT, [P, I64, P, P, SZ, P]),
     "gsat_long_row_partial_floats": (SZ, [I64, I64]),
@@ -66,6 +66,10 @@ SIGNATURES = {
     "gsat_line_graph_pair_counts": (INT, [P, I64, P, P]),
     "gsat_line_graph": (INT, [P, P, P, I64, I64, P, P]),
     "gsat_narrow_i64": (INT, [P, I64, P, P]),
+    "gsat_und_edges_workspace_bytes": (SZ, [I64]),
+    "gsat_und_edges": (INT, [P, I64, I64, P, P, P, P, P, P, P, P, SZ, P]),
+    "gsat_und_line_graph_counts": (INT, [P, P, P, P, I64, P, P]),
+    "gsat_und_line_graph": (INT, [P, P, P, P, P, I64, I64, P, P]),
     "gsat_segment_pool_fwd": (INT, [P, P, I64, I64, INT, P, P]),
     "gsat_segment_pool_bwd": (INT, [P, P, I64, I64, INT, P, P]),
 }

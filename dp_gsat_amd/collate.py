@@ -74,3 +74,55 @@ def line_graph(edge_index: torch.Tensor, num_nodes: int, batch: Optional[torch.T
     call("gsat_line_graph", ptr(ix.rowptr_src), ptr(ix.eid_by_src), ptr(pair_ptr), num_nodes, num_pairs, ptr(dual_ei), stream())
     dual_batch = None if batch is None else batch[edge_index[0]]
     return dual_ei, dual_batch
+
+
+def line_graph_undirected(edge_index: torch.Tensor, num_nodes: int, batch: Optional[torch.Tensor] = None,
+                          x: Optional[torch.Tensor] = None, motif_start: Optional[int] = None):
+    """Dual graph with one node per UNDIRECTED primal edge, on the device -- the rule of the fork's ba_2motifs dual dataset
+    (src/datasets/ba_2motifs_dual.py:35-62): edges numbered by (smaller, larger) endpoint in row-major order, dual nodes
+    adjacent when the primal edges share an endpoint, dual edge list in (i, j) row-major order.
+
+    Returns a ``Batch`` with ``edge_index`` (dual, int64 [2, E_d]), ``und_index`` (int64 [2, M]: endpoints a < b of every dual
+    node), ``und_of_edge`` (int64 [E]: dual node of every primal directed edge, -1 for self loops), and when the inputs are
+    given: ``batch`` (graph of every dual node), ``x`` = [x[a] || x[b]] (:48) and ``node_label`` = 1 iff both endpoints have
+    local id >= ``motif_start`` (:46-47, 20 for BA-2motifs).  Raises ValueError if some edge has no reverse."""
+    from .graph_index import call_size
+    if edge_index.dim() != 2 or edge_index.shape[0] != 2 or edge_index.dtype != torch.int64:
+        raise ValueError("edge_index must be an int64 tensor of shape [2, E]")
+    ei = edge_index.contiguous()
+    dev, E, N = ei.device, int(ei.shape[1]), int(num_nodes)
+    i32 = lambda n: torch.empty(max(int(n), 1), dtype=torch.int32, device=dev)
+    keys = torch.empty(max(E, 1), dtype=torch.int64, device=dev)          # uint64 keys: same bytes
+    rowptr, und_of_slot, und_of_edge, und_src, und_dst = i32(N + 1), i32(E), i32(E), i32(E), i32(E)
+    status = torch.zeros(4, dtype=torch.int32, device=dev)
+    wb = max(call_size("gsat_und_edges_workspace_bytes", E), 256)
+    ws = torch.empty(wb, dtype=torch.uint8, device=dev)
+    call("gsat_und_edges", ptr(ei), E, N, ptr(keys), ptr(rowptr), ptr(und_of_slot), ptr(und_of_edge), ptr(und_src), ptr(und_dst),
+         ptr(status), ptr(ws), wb, stream())
+    M, asym, bad = status[:3].tolist()
+    if bad:
+        raise ValueError("edge_index contains node ids outside [0, num_nodes)")
+    if asym:
+        raise ValueError("line_graph_undirected needs a symmetric edge set: %d directed edges have no reverse" % asym)
+    counts = torch.zeros(M, dtype=torch.int64, device=dev)
+    call("gsat_und_line_graph_counts", ptr(rowptr), ptr(und_of_slot), ptr(und_src), ptr(und_dst), M, ptr(counts), stream())
+    dual_ptr = torch.cat([torch.zeros(1, dtype=torch.int64, device=dev), counts.cumsum(0)])
+    total = int(dual_ptr[-1].item())
+    dual_ei = torch.empty(2, total, dtype=torch.int64, device=dev)
+    call("gsat_und_line_graph", ptr(rowptr), ptr(und_of_slot), ptr(und_src), ptr(und_dst), ptr(dual_ptr), M, total, ptr(dual_ei), stream())
+    a, b = und_src[:M].long(), und_dst[:M].long()
+    out = Batch(edge_index=dual_ei, und_index=torch.stack([a, b]), und_of_edge=und_of_edge[:E].long(), batch=None, x=None,
+                node_label=None, edge_attr=None, num_dual_nodes=M)
+    if batch is not None:
+        out.batch = batch[a]
+    if x is not None:
+        out.x = torch.cat([x[a], x[b]], dim=1)
+    if motif_start is not None:
+        if batch is None:
+            raise ValueError("motif labels need the batch vector (local node ids)")
+        G = int(batch.max().item()) + 1 if batch.numel() else 0
+        node_ptr = torch.zeros(G + 1, dtype=torch.int64, device=dev)
+        node_ptr[1:] = torch.bincount(batch, minlength=G).cumsum(0)
+        la, lb = a - node_ptr[batch[a]], b - node_ptr[batch[b]]
+        out.node_label = ((la >= motif_start) & (lb >= motif_start)).float()
+    return out

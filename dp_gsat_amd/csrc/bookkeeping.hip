@@ -89,7 +89,7 @@ __global__ void k_segments(const int64_t* __restrict__ ids, int64_t n, int64_t n
         int64_t v = ids[i];
         bool bad = v < 0 || v >= num_seg || (i > 0 && ids[i - 1] > v);
         if (bad) atomicAdd(flags, 1);
-        ids32[i] = (int32_t)v;
+        ids32[i] = (int32_t)(v < 0 ? 0 : (v >= num_seg ? num_seg - 1 : v));      // clamped: row_seg lookups stay in bounds
     }
     if (i <= num_seg) {
         int64_t lo = 0, hi = n;
@@ -101,10 +101,13 @@ __global__ void k_segments(const int64_t* __restrict__ ids, int64_t n, int64_t n
     }
 }
 
-__global__ void k_gather_i64(const int64_t* __restrict__ table, const int64_t* __restrict__ index, int64_t n,
+__global__ void k_gather_i64(const int64_t* __restrict__ table, int64_t table_len, const int64_t* __restrict__ index, int64_t n,
                              int64_t* __restrict__ out) {
     int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n) out[i] = table[index[i]];
+    if (i >= n) return;
+    int64_t j = index[i];
+    j = j < 0 ? 0 : (j >= table_len ? table_len - 1 : j);       // clamped like the CSR builders (range errors are counted there)
+    out[i] = table[j];
 }
 
 struct ChunkCount {      // number of GSAT_LONG_ROW_EDGES-sized chunks of row r (0 for short rows and for r == num_rows)
@@ -140,8 +143,8 @@ __global__ void k_make_pair_keys(const int64_t* __restrict__ ei, int64_t E, int6
     keys[E + e] = (uint32_t)(N + s);
     ids[e] = (int32_t)e;
     ids[E + e] = (int32_t)e;
-    if (src32) src32[e] = (int32_t)ei[e];
-    if (dst32) dst32[e] = (int32_t)ei[E + e];
+    if (src32) src32[e] = (int32_t)s;        // the clamped ids: every consumer stays in bounds even if the host never reads err[0]
+    if (dst32) dst32[e] = (int32_t)d;
 }
 
 __global__ void k_pair_rowptrs(const uint32_t* __restrict__ sorted, int64_t E, int64_t N, int32_t* __restrict__ rowptr_dst,
@@ -165,13 +168,19 @@ __global__ void k_pair_gather(const int64_t* __restrict__ ei, const int32_t* __r
     int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (k >= 2 * E) return;
     const int32_t e = perm[k];
-    if (k < E) { eid_by_dst[k] = e; src_by_dst[k] = (int32_t)ei[e]; return; }
+    // out-of-range ids are clamped to N-1 exactly as k_make_pair_keys clamped their sort keys (and counted them in err_flag[0]),
+    // so the CSRs stay self-consistent and memory-safe whether or not the host reads the counter
+    if (k < E) {
+        const int64_t sraw = ei[e];
+        eid_by_dst[k] = e;
+        src_by_dst[k] = (int32_t)((sraw < 0 || sraw >= num_nodes) ? num_nodes - 1 : sraw);
+        return;
+    }
     const int64_t draw = ei[E + e];
-    const int32_t d = (int32_t)draw;
+    const int32_t d = (int32_t)((draw < 0 || draw >= num_nodes) ? num_nodes - 1 : draw);
     eid_by_src[k - E] = e;
     dst_by_src[k - E] = d;
     // slot of edge e in the by-destination CSR: row d holds its edge ids in ascending order in perm[rowptr_dst[d] .. rowptr_dst[d+1])
-    if (draw < 0 || draw >= num_nodes) { slot_dst_of_srcslot[k - E] = 0; return; }      // reported through err_flag[0] by k_make_pair_keys
     int lo = rowptr_dst[d], hi = rowptr_dst[d + 1];
     while (lo < hi) {
         const int mid = (lo + hi) >> 1;
@@ -396,12 +405,12 @@ int gsat_segment_ptr32(const int64_t* seg_ids, int64_t n, int64_t num_seg, int32
     return GSAT_OK;
 }
 
-int gsat_gather_i64(const int64_t* table, const int64_t* index, int64_t n, int64_t* out, void* stream_) {
+int gsat_gather_i64(const int64_t* table, int64_t table_len, const int64_t* index, int64_t n, int64_t* out, void* stream_) {
     hipStream_t stream = (hipStream_t)stream_;
-    GSAT_REQUIRE(n >= 0, GSAT_ERR_ARG, "gsat_gather_i64: bad n");
+    GSAT_REQUIRE(n >= 0 && table_len >= 0, GSAT_ERR_ARG, "gsat_gather_i64: bad n");
     if (n == 0) return GSAT_OK;
-    GSAT_REQUIRE(table && index && out, GSAT_ERR_ARG, "gsat_gather_i64: null pointer");
-    k_gather_i64<<<ceil_div(n, 256), 256, 0, stream>>>(table, index, n, out);
+    GSAT_REQUIRE(table && index && out && table_len > 0, GSAT_ERR_ARG, "gsat_gather_i64: null pointer / empty table");
+    k_gather_i64<<<ceil_div(n, 256), 256, 0, stream>>>(table, table_len, index, n, out);
     GSAT_LAUNCH_CHECK();
     return GSAT_OK;
 }

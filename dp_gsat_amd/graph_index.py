@@ -21,6 +21,7 @@ from ._lib import call, ptr, stream
 # Sync-free mode: nothing in the step reads device memory back on the host (no `if is_undirected`, no hub-row count),
 # so a whole step can be captured into a hipGraph (torch.cuda.graph) and replayed; decisions move into the kernels.
 _SYNC_FREE = False
+_VALIDATED: set = set()       # batches already validated in sync-free mode (BatchIndex._validate_once)
 
 
 def set_sync_free(flag: bool) -> None:
@@ -97,6 +98,8 @@ class BatchIndex:
         self._rev_flags = None
         self._undirected = None
         self._graphs = {}
+        if _SYNC_FREE:
+            self._validate_once()
 
     @property
     def long_rows(self):
@@ -105,11 +108,8 @@ class BatchIndex:
         (per collated batch), merged with the undirected-flag read when that one is needed too."""
         if _SYNC_FREE and self._long is None:
             return (self.chunk_ptr_dst, self.chunk_ptr_src)            # always run the (early-exit) hub-chunk launch
-        if self._long is None:
-            if self.E <= 256:
-                self._long = (False, False)
-            else:
-                self._readback()
+        if self._long is None or not self._checked:
+            self._readback()                     # also for tiny batches: one 32-byte copy answers every host-side question
         return (self.chunk_ptr_dst if self._long[0] else None, self.chunk_ptr_src if self._long[1] else None)
 
     def partial(self, H: int) -> torch.Tensor:
@@ -121,6 +121,19 @@ class BatchIndex:
             buf = torch.empty(n, dtype=torch.float32, device=self.device)
             self._partials[H] = buf
         return buf
+
+    def _validate_once(self):
+        """Sync-free mode never reads the status words inside the step.  The kernels are memory-safe on bad input (ids are
+        clamped), but the caller still deserves the ValueError: validate each distinct batch ONCE, outside stream capture
+        (the warm-up runs that precede a capture), and never again for the same tensors."""
+        key = (self.edge_index.data_ptr(), tuple(self.edge_index.shape), self.N,
+               tuple((k[0], k[2]) for k in self._graphs))
+        if key in _VALIDATED or torch.cuda.is_current_stream_capturing():
+            return
+        self._readback()
+        if len(_VALIDATED) > 4096:
+            _VALIDATED.clear()
+        _VALIDATED.add(key)
 
     # -- validation (one host sync, deferred until something needs a host-side decision) --------
     def check(self):
@@ -147,9 +160,13 @@ class BatchIndex:
             self._err[1:3] = torch.cat([self.chunk_ptr_dst[-1:], self.chunk_ptr_src[-1:]])
         vals = self._err.tolist()              # every status word of this batch in one copy, no gather kernel
         self._long = (vals[1] > 0, vals[2] > 0)
+        self._checked = True
         if vals[0] != 0:
             raise ValueError("edge_index contains node ids outside [0, num_nodes)")
-        self._checked = True
+        if vals[3] != 0:
+            # the reference's scatter-based InstanceNorm / pools accept any order; PyG collation always yields a sorted vector
+            # and the segment pointers here are binary searches over it, so anything else is rejected instead of mis-normalised
+            raise ValueError("`batch` must be non-decreasing with ids in [0, num_graphs)")
         if self._rev_flags is not None:
             self._undirected = bool(vals[4])
             self._rev = self._rev_dev if self._undirected else None
@@ -186,8 +203,12 @@ class BatchIndex:
         key = (batch.data_ptr(), batch._version, int(batch.shape[0]))
         seg = self._graphs.get(key)
         if seg is None:
+            self._err[3:4].zero_()                 # the order / range counter belongs to the batch vector being registered
             seg = GraphSegments(self, batch, num_graphs)
             self._graphs = {key: seg}
+            self._checked = False                  # the next host-side decision re-reads the status words, now including [3]
+            if _SYNC_FREE:
+                self._validate_once()
         return seg
 
 
@@ -212,8 +233,8 @@ class GraphSegments:
         self._edge = None
 
     def check(self):
-        if int(self._flags.item()) != 0:
-            raise ValueError("`batch` must be non-decreasing with ids in [0, num_graphs)")
+        self.index._checked = False
+        self.index.check()
 
     @property
     def edge_segments(self):
@@ -223,7 +244,7 @@ class GraphSegments:
             ix = self.index
             E, dev = ix.E, ix.device
             eg = torch.empty(max(E, 1), dtype=torch.int64, device=dev)[:E]
-            call("gsat_gather_i64", ptr(self.batch), ptr(ix.edge_index[0].contiguous()), E, ptr(eg), stream())
+            call("gsat_gather_i64", ptr(self.batch), int(self.batch.shape[0]), ptr(ix.edge_index[0].contiguous()), E, ptr(eg), stream())
             ws_bytes = max(call_size("gsat_csr_workspace_bytes", E, self.G), 256)
             ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
             eptr = torch.empty(self.G + 1, dtype=torch.int32, device=dev)

@@ -48,6 +48,8 @@ class PNA(nn.Module):
 
     def get_emb(self, x, edge_index, batch, edge_attr, edge_atten=None):
         index = get_index(edge_index, x.shape[0])
+        if batch is not None:
+            index.graphs(batch)        # register the batch vector first: one status read-back then validates ids AND order
         x = self.node_encoder(x)
         if edge_attr is not None:
             edge_attr = self.edge_encoder(edge_attr)

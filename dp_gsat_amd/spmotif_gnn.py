@@ -36,6 +36,8 @@ class SPMotifNet(nn.Module):
 
     def get_node_reps(self, x, edge_index, edge_attr, batch, edge_atten):
         index = get_index(edge_index, x.shape[0])
+        if batch is not None:
+            index.graphs(batch)        # register the batch vector first: one status read-back then validates ids AND order
         x = self.node_emb(x)
         for conv, relu in zip(self.convs, self.relus):
             x = relu(conv(x=x, edge_index=edge_index, edge_weight=edge_attr, edge_atten=edge_atten, index=index))

@@ -190,6 +190,21 @@ def mutag_batch(npz_path: str, num_graphs: Optional[int] = None) -> Batch:
                  edge_attr=None, y=torch.from_numpy(y.astype(np.float32)).view(-1, 1), num_graphs=G)
 
 
+def mutag_full_topology(npz_path: str):
+    """The whole Mutagenicity file of the reference (data/mutag_dual/raw: 4337 graphs, 131 488 nodes, 266 894 directed edges)
+    from the committed fixture tests/golden/mutag_full.npz: (edge_index int64 [2,E] in file order, batch int64 [N], kept mask)."""
+    z = np.load(npz_path)
+    s = np.cumsum(z["even_src_delta"].astype(np.int64))
+    d = s + z["even_dst_minus_src"].astype(np.int64)
+    E = 2 * len(s)
+    ei = np.empty((2, E), dtype=np.int64)
+    ei[0, 0::2], ei[1, 0::2] = s, d            # edge 2k
+    ei[0, 1::2], ei[1, 1::2] = d, s            # edge 2k+1 is its reverse
+    sizes = z["nodes_per_graph"].astype(np.int64)
+    batch = np.repeat(np.arange(len(sizes), dtype=np.int64), sizes)
+    return torch.from_numpy(ei), torch.from_numpy(batch), torch.from_numpy(z["kept_mask"].astype(np.int64))
+
+
 def in_degree_histogram(b: Batch, minlength: int = 10) -> torch.Tensor:
     """``deg`` handed to PNA: bincount of in-degrees, minlength 10 (src/utils/get_data_loaders.py:99-101)."""
     d = torch.bincount(b.edge_index[1].cpu(), minlength=b.num_nodes)

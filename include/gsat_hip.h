@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define GSAT_ABI_VERSION 1
+#define GSAT_ABI_VERSION 2
 
 #define GSAT_OK 0
 #define GSAT_ERR_HIP (-1)        /* a HIP runtime call failed */
@@ -99,8 +99,9 @@ int gsat_segment_ptr(const int64_t* seg_ids, int64_t num_rows, int64_t num_segme
 int gsat_segment_ptr32(const int64_t* seg_ids, int64_t n, int64_t num_segments, int32_t* ptr, int32_t* seg_ids32,
                        int32_t* flags, void* stream);
 
-/* out[e] = batch[index[e]]  (edge -> graph id, `batch[col]` of example/gsat.py:136). int64 out. */
-int gsat_gather_i64(const int64_t* table, const int64_t* index, int64_t n, int64_t* out, void* stream);
+/* out[e] = batch[index[e]]  (edge -> graph id, `batch[col]` of example/gsat.py:136). int64 out; index values outside
+ * [0, table_len) are clamped into the table (they are counted as range errors by the CSR builders). */
+int gsat_gather_i64(const int64_t* table, int64_t table_len, const int64_t* index, int64_t n, int64_t* out, void* stream);
 
 /* ============================ masked message passing: sum (GIN / GINE) ====================== */
 
@@ -425,6 +426,28 @@ int gsat_collate(const int64_t* graph_ids, int64_t num_graphs, const int64_t* no
 int gsat_line_graph_pair_counts(const int32_t* rowptr_src, int64_t num_nodes, int64_t* counts, void* stream);
 int gsat_line_graph(const int32_t* rowptr_src, const int32_t* eid_by_src, const int64_t* pair_ptr, int64_t num_nodes,
                     int64_t num_pairs, int64_t* dual_edge_index, void* stream);
+
+/*
+ * Line graph with one dual node per UNDIRECTED primal edge (the ba_2motifs dual dataset of the fork).
+ * Undirected edges are numbered in row-major order of (smaller endpoint, larger endpoint); dual nodes i != j are adjacent
+ * when their primal edges share an endpoint; dual_edge_index is in (i, j) row-major order (dense_to_sparse order).
+ * replaces: the dense-matrix Python loops of src/datasets/ba_2motifs_dual.py:35-62.
+ * Step 1, gsat_und_edges: sorted_keys uint64[E] (src*N+dst ascending), rowptr int32[N+1] over that list, und_of_slot int32[E]
+ *   (undirected id of every sorted slot, -1 for self loops), und_of_edge int32[E] (same by ORIGINAL edge id: maps primal edge
+ *   attention onto dual nodes), und_src/und_dst int32[>= E/2 + 1, pass E] endpoints a < b of every undirected edge,
+ *   status int32[4]: [0] = M (number of undirected edges), [1] = directed edges whose reverse is missing (must be 0: the rule is
+ *   defined on symmetric edge sets), [2] = out-of-range ids (clamped).
+ * Step 2, gsat_und_line_graph_counts: counts[i] = dual degree of dual node i (the caller scans them into dual_ptr int64[M+1]).
+ * Step 3, gsat_und_line_graph: fills dual_edge_index int64[2, total], total = dual_ptr[M].
+ */
+size_t gsat_und_edges_workspace_bytes(int64_t num_edges);
+int gsat_und_edges(const int64_t* edge_index, int64_t num_edges, int64_t num_nodes, uint64_t* sorted_keys, int32_t* rowptr,
+                   int32_t* und_of_slot, int32_t* und_of_edge, int32_t* und_src, int32_t* und_dst, int32_t* status,
+                   void* workspace, size_t workspace_bytes, void* stream);
+int gsat_und_line_graph_counts(const int32_t* rowptr, const int32_t* und_of_slot, const int32_t* und_src, const int32_t* und_dst,
+                               int64_t num_und, int64_t* counts, void* stream);
+int gsat_und_line_graph(const int32_t* rowptr, const int32_t* und_of_slot, const int32_t* und_src, const int32_t* und_dst,
+                        const int64_t* dual_ptr, int64_t num_und, int64_t total, int64_t* dual_edge_index, void* stream);
 
 /* ================================ global pools / segment ops ================================ */
 

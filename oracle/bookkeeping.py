@@ -136,3 +136,52 @@ def line_graph_by_source(edge_index):
                 out.append((group[i], group[j]))
                 out.append((group[j], group[i]))
     return np.asarray(out, dtype=np.int64).reshape(-1, 2).T
+
+
+def line_graph_undirected(edge_index, batch, x=None, motif_start=20):
+    """Dual graph of the fork's ba_2motifs dual dataset, restating src/datasets/ba_2motifs_dual.py:35-62 loop by loop on the
+    dense adjacency matrix of every graph of a collated batch (the reference works on the dataset's [G, n, n] dense array):
+      :42-50  scan (node1, node2) row-major; an un-numbered edge gets the next edge number in BOTH cells, its label is 1 iff
+              node1 >= 20 and node2 >= 20 (motif nodes), its feature is x[node1] || x[node2];
+      :52-57  for every row, all ordered pairs i != j of the edge numbers in that row become dual edges;
+      :68     dense_to_sparse([3P]: nonzero in row-major order) lists them.
+    Returns (dual_edge_index [2, E_d] with dual ids offset per graph, und_index [2, M] global endpoints, dual_batch [M],
+    dual_x or None, dual_label [M])."""
+    ei = _np(edge_index).astype(np.int64)
+    b = _np(batch).astype(np.int64)
+    xs = None if x is None else _np(x)
+    ptr = graph_ptr(b)
+    e_graph = b[ei[0]]
+    dual_ei, und, dbatch, dx, dlabel = [], [], [], [], []
+    off = 0
+    for g in range(len(ptr) - 1):
+        n0, n = int(ptr[g]), int(ptr[g + 1] - ptr[g])
+        sel = e_graph == g
+        graph = np.zeros((n, n), dtype=np.int64)
+        graph[ei[0, sel] - n0, ei[1, sel] - n0] = 1                      # to_dense_adj
+        graph -= 2                                                       # :40
+        edge_num = 0
+        for node1 in range(n):                                           # :44
+            for node2 in range(n):
+                if graph[node1][node2] == -1 and node1 != node2:         # :46
+                    graph[node1][node2] = edge_num
+                    graph[node2][node1] = edge_num
+                    dlabel.append(1.0 if (node1 >= motif_start and node2 >= motif_start) else 0.0)   # :49-50
+                    if xs is not None:
+                        dx.append(np.concatenate((xs[n0 + node1], xs[n0 + node2]), axis=0))            # :51
+                    und.append((n0 + node1, n0 + node2))
+                    dbatch.append(g)
+                    edge_num += 1
+        dual_dense = np.zeros((edge_num, edge_num), dtype=np.int64)
+        for row in graph:                                                # :55
+            edges = row[row != -2]
+            for i in edges:
+                for j in edges:
+                    if i != j:
+                        dual_dense[int(i), int(j)] = 1
+        r, c = np.nonzero(dual_dense)                                    # dense_to_sparse
+        dual_ei.append(np.stack([r + off, c + off]))
+        off += edge_num
+    dei = np.concatenate(dual_ei, axis=1) if dual_ei else np.zeros((2, 0), dtype=np.int64)
+    return (dei.astype(np.int64), np.asarray(und, dtype=np.int64).reshape(-1, 2).T, np.asarray(dbatch, dtype=np.int64),
+            None if xs is None else np.stack(dx), np.asarray(dlabel, dtype=np.float32))

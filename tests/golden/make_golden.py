@@ -54,6 +54,17 @@ def make_mutag():
     ei = np.stack([new_id[A[sel, 0]], new_id[A[sel, 1]]])
     np.savez_compressed(f"{HERE}/mutag128.npz", edge_index=ei.astype(np.int32), batch=np.asarray(batch, dtype=np.int32),
                         node_label=np.asarray(labels, dtype=np.int8), y=gl[kept].astype(np.int8))
+    # 3. the WHOLE file's topology (all 4337 graphs, 266 894 directed edges) for the reference-held known answers:
+    #    the in-degree histogram, "edge 2k+1 reverses edge 2k", and the dual-edge count the reference's author recorded
+    #    next to the pair loops (`# len dual_edges: 451808`, src/datasets/mutag_dual.py:385).  Only the even edges are stored
+    #    (the odd ones are their reverses, asserted above); ids are delta-coded so the npz stays small.
+    assert facts["pairs_are_reverses"] and facts["graph_indicator_sorted"]
+    even = A[0::2].astype(np.int64)
+    np.savez_compressed(f"{HERE}/mutag_full.npz", even_src_delta=np.diff(even[:, 0], prepend=0).astype(np.int32),
+                        even_dst_minus_src=(even[:, 1] - even[:, 0]).astype(np.int32),
+                        nodes_per_graph=np.bincount(gi, minlength=G).astype(np.int32), kept_mask=mask.astype(np.int8))
+    facts["line_graph_directed_dual_edges"] = 451808           # the reference's own recorded value (mutag_dual.py:385)
+    facts["line_graph_rule"] = "pairs of directed edges sharing their FIRST endpoint, both orders (mutag_dual.py:345-377)"
     with open(f"{HERE}/mutag_facts.json", "w") as f:
         json.dump(facts, f, indent=1)
     print("mutag128:", ei.shape, off, facts)

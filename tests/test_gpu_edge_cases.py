@@ -88,6 +88,46 @@ def test_error_behaviour(dev):
         gine(torch.randn(2, 16, device=dev), ei, edge_attr=torch.randn(2, 3, device=dev))
 
 
+def test_bad_ids_are_reported_without_an_explicit_check(dev):
+    """out-of-range ids and unsorted batch vectors must surface as ValueError on the normal call path (no explicit
+    .check()), also for E <= 256, and must never reach a kernel unclamped (no fault, in eager and in sync-free mode)."""
+    import dp_gsat_amd as G
+    from dp_gsat_amd.ops import masked_sum_aggregate
+    G.clear_cache()
+    ei = torch.tensor([[0, 3, 1], [1, 0, 2]], device=dev)                   # id 3 == N: out of range, E <= 256
+    x = torch.randn(3, 16, device=dev)
+    with pytest.raises(ValueError, match="outside"):
+        masked_sum_aggregate(x, G.get_index(ei, 3), torch.rand(3, 1, device=dev))
+    # the index built from the bad ids is memory-safe: every stored id is inside [0, N)
+    ix = G.BatchIndex(ei, 3)
+    for t in (ix.src32, ix.dst32, ix.src_by_dst, ix.dst_by_src):
+        assert int(t.min()) >= 0 and int(t.max()) < 3
+    # a permuted batch vector through GSAT.forward_pass: ValueError, not silently wrong norms
+    from dp_gsat_amd.synth import Batch
+    from tests.graphs import random_batch
+    ei3, batch3, n3 = random_batch(5, 3, 4, 9)
+    bad_batch = batch3.flip(0).contiguous()                                    # same multiset of ids, wrong order
+    bad = Batch(x=torch.randn(n3, 8), edge_index=ei3, batch=bad_batch, edge_attr=None, y=torch.ones(3, 1),
+                num_graphs=3).to(dev)
+    cfg = dict(model_name="GIN", n_layers=2, hidden_size=16, dropout_p=0.0, use_edge_attr=False)
+    clf = G.get_model(8, 0, 2, False, cfg, dev)
+    gsat = G.GSAT(clf, G.ExtractorMLP(16, True).to(dev), G.Criterion(2, False), None, learn_edge_att=True).train()
+    G.clear_cache()
+    with pytest.raises(ValueError, match="non-decreasing"):
+        gsat.forward_pass(bad, 0, True)
+    G.clear_cache()
+    G.set_sync_free(True)
+    try:
+        with pytest.raises(ValueError, match="non-decreasing"):          # validated once, outside capture
+            gsat.forward_pass(bad, 0, True)
+        G.clear_cache()
+        with pytest.raises(ValueError, match="outside"):
+            masked_sum_aggregate(x, G.get_index(ei.clone(), 3), torch.rand(3, 1, device=dev))
+    finally:
+        G.set_sync_free(False)
+        G.clear_cache()
+
+
 @pytest.mark.parametrize("workload", ["c1", "c2", "c3", "c4"])
 def test_scope_a_at_baseline_size(dev, workload):
     """The bench's scope-A step at BASELINE.json's full batch sizes vs the oracle on the same seeded inputs
@@ -213,3 +253,65 @@ def test_line_graph_bit_exact(dev):
     d2 = G.line_graph(ei2.to(dev), N)[0].cpu().numpy()
     key = lambda a: np.sort(a[0] * ei.shape[1] + a[1])
     assert np.array_equal(key(d2), key(w2))
+
+
+def test_whole_mutag_file_reference_recorded_answers(dev):
+    """The HIP bookkeeping against numbers the REFERENCE holds (not the oracle): whole Mutagenicity file, in-degree histogram
+    [2401, 64058, 7570, 42140, 15319] and `edge 2k+1 reverses edge 2k` (data/mutag_dual/raw), and the dual-edge count
+    recorded by the reference's author next to the pair loops: `# len dual_edges: 451808` (src/datasets/mutag_dual.py:385)."""
+    import os
+    import dp_gsat_amd as G
+    from dp_gsat_amd.synth import mutag_full_topology
+    ei, batch, kept = mutag_full_topology(os.path.join(os.path.dirname(__file__), "golden", "mutag_full.npz"))
+    N, E = int(batch.shape[0]), int(ei.shape[1])
+    assert (N, E) == (131488, 266894)
+    ix = G.BatchIndex(ei.to(dev), N)
+    indeg = (ix.rowptr_dst[1:] - ix.rowptr_dst[:-1]).long()
+    assert torch.bincount(indeg).tolist() == [2401, 64058, 7570, 42140, 15319]
+    assert int(ix.rowptr_dst[-1]) == E and int(ix.rowptr_src[-1]) == E
+    assert ix.is_undirected
+    rev = ix.rev.cpu().long()
+    assert torch.equal(rev[0::2], torch.arange(1, E, 2)) and torch.equal(rev[1::2], torch.arange(0, E, 2))
+    dei, dbatch = G.line_graph(ei.to(dev), N, batch.to(dev))
+    assert tuple(dei.shape) == (2, 451808)
+    # file order is source-sorted, so the device order equals the reference's group order: bit-exact against the pair loops
+    assert bool((ei[0][1:] >= ei[0][:-1]).all())
+    assert np.array_equal(dei.cpu().numpy(), obk.line_graph_by_source(ei))
+    seg = ix.graphs(batch.to(dev), 4337)
+    assert torch.equal(seg.node_ptr.cpu().long(), torch.from_numpy(obk.graph_ptr(batch, 4337)))
+
+
+def test_undirected_line_graph_bit_exact(dev):
+    """The ba_2motifs dual rule (src/datasets/ba_2motifs_dual.py:35-62) on the device vs the oracle's loop-by-loop restatement."""
+    import dp_gsat_amd as G
+    from dp_gsat_amd.synth import ba2motifs_batch
+    from tests.graphs import random_batch, shuffle_edges
+    d = ba2motifs_batch(num_graphs=64, seed=11)
+    ei = shuffle_edges(d.edge_index, 3)                                 # edge order must not matter
+    want = obk.line_graph_undirected(ei, d.batch, d.x, motif_start=20)
+    got = G.line_graph_undirected(ei.to(dev), d.num_nodes, d.batch.to(dev), d.x.to(dev), motif_start=20)
+    assert np.array_equal(got.edge_index.cpu().numpy(), want[0])
+    assert np.array_equal(got.und_index.cpu().numpy(), want[1])
+    assert np.array_equal(got.batch.cpu().numpy(), want[2])
+    assert np.array_equal(got.x.cpu().numpy(), want[3])
+    assert np.array_equal(got.node_label.cpu().numpy(), want[4])
+    # und_of_edge: both directions of an edge map to the same dual node, whose endpoints are the edge's endpoints
+    u = got.und_of_edge.cpu()
+    und = got.und_index.cpu()
+    lo, hi = torch.minimum(ei[0], ei[1]), torch.maximum(ei[0], ei[1])
+    assert torch.equal(und[0][u], lo) and torch.equal(und[1][u], hi)
+    # ragged molecule-like graphs with isolated nodes and duplicated edges (the dense adjacency of the reference dedupes them)
+    ei2, b2, n2 = random_batch(21, 9, 2, 17)
+    ei2 = torch.cat([ei2, ei2[:, :4]], dim=1)
+    w2 = obk.line_graph_undirected(ei2, b2, None)
+    g2 = G.line_graph_undirected(ei2.to(dev), n2, b2.to(dev))
+    assert np.array_equal(g2.edge_index.cpu().numpy(), w2[0]) and np.array_equal(g2.und_index.cpu().numpy(), w2[1])
+    # a self loop is no dual node (`node1 != node2`, :46) and does not disturb the others (the reference's loops would index
+    # dual_dense[-1] through it; BA-2motifs has none, so that quirk is not reproduced)
+    ei3 = torch.cat([ei2, torch.tensor([[1], [1]])], dim=1)
+    g3 = G.line_graph_undirected(ei3.to(dev), n2, b2.to(dev))
+    assert int(g3.und_of_edge[-1]) == -1 and torch.equal(g3.edge_index, g2.edge_index)
+    with pytest.raises(ValueError, match="symmetric"):
+        G.line_graph_undirected(torch.tensor([[0, 1], [1, 2]], device=dev), 3)
+    empty = G.line_graph_undirected(torch.zeros(2, 0, dtype=torch.int64, device=dev), 3)
+    assert empty.edge_index.shape == (2, 0) and empty.num_dual_nodes == 0
