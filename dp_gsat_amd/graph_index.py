@@ -81,7 +81,7 @@ class BatchIndex:
                 inv = torch.empty(E, dtype=torch.int32, device=dev)
                 inv[self.eid_by_dst.long()] = torch.arange(E, dtype=torch.int32, device=dev)
                 self._slot_dst_of_srcslot.copy_(inv[self.eid_by_src.long()])
-            self._partials, self._long = {}, None
+            self._partials, self._long, self._tiles = {}, None, {}
             self._checked, self._rev, self._rev_dev, self._rev_flags, self._undirected, self._graphs = False, None, None, None, None, {}
             return
         ws_bytes = max(call_size("gsat_csr_pair_workspace_bytes", E, N), 256)
@@ -91,6 +91,7 @@ class BatchIndex:
              ptr(self.chunk_ptr_dst), ptr(self.chunk_ptr_src), ptr(self.src32), ptr(self.dst32), ptr(self._err), ptr(ws), ws_bytes,
              stream())
         self._partials = {}
+        self._tiles = {}
         self._long = None
         self._checked = False
         self._rev = None
@@ -197,6 +198,29 @@ class BatchIndex:
     def slot_dst_of_srcslot(self) -> torch.Tensor:
         """For slot k of the by-source CSR, the slot of the same edge in the by-destination CSR."""
         return self._slot_dst_of_srcslot
+
+    # -- destination-row windows of the tiled PNA backward -----------------------------------------
+    def pna_tiles(self, H: int):
+        """(tile_ptr int32[T+1], T, rows_cap, edges_cap) for width H, or None when the tiled backward does not cover H.
+        Windows are aligned to graph starts when a batch vector has been registered (graphs()), else fixed."""
+        import ctypes
+        seg = next(iter(self._graphs.values())) if self._graphs else None
+        key = (int(H), id(seg))
+        hit = self._tiles.get(key)
+        if hit is not None:
+            return hit
+        nominal, slack, ecap = ctypes.c_int32(), ctypes.c_int32(), ctypes.c_int32()
+        budget = int(os.environ.get("GSAT_PNA_TILE_LDS", "0"))
+        if _lib.load().gsat_pna_tile_plan(int(H), budget, ctypes.byref(nominal), ctypes.byref(slack), ctypes.byref(ecap)) != 0:
+            self._tiles[key] = False
+            return False
+        T = (self.N + nominal.value - 1) // nominal.value
+        tile_ptr = torch.empty(T + 1, dtype=torch.int32, device=self.device)
+        call("gsat_pna_build_tiles", ptr(seg.node_ptr) if seg is not None else None, ptr(seg.node_seg32) if seg is not None else None,
+             self.N, nominal.value, slack.value, ptr(tile_ptr), stream())
+        out = (tile_ptr, T, nominal.value + slack.value, ecap.value)
+        self._tiles = {key: out}
+        return out
 
     # -- per-graph segments ----------------------------------------------------------------------
     def graphs(self, batch: torch.Tensor, num_graphs: Optional[int] = None) -> "GraphSegments":

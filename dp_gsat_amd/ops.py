@@ -5,6 +5,7 @@ provides the device memory.  None of these has a CPU path.
 """
 from __future__ import annotations
 
+import os
 from typing import Optional
 
 import torch
@@ -105,6 +106,8 @@ def segment_pool(x, segments, mean: bool):
 
 
 AGGREGATOR_CODES = {"sum": 0, "mean": 1, "min": 2, "max": 3, "var": 4, "std": 5}
+# the aggregator / scaler lists of the reference's PNA YAMLs (src/configs/PNA-*.yml): covered by the tiled backward
+_FIXED_PNA = {((1, 2, 3, 5), (0,)): True, ((1, 2, 3, 5, 0), (0,)): True}
 SCALER_CODES = {"identity": 0, "amplification": 1, "attenuation": 2, "linear": 3, "inverse_linear": 4}
 
 
@@ -151,9 +154,21 @@ class PnaAggregate(torch.autograd.Function):
         need_att = attf is not None and ctx.needs_input_grad[1]
         need_ee = edge_emb is not None and ctx.needs_input_grad[2]
         dev = x.device
-        dx_self = torch.empty_like(x)
         dmsg = torch.empty(max(index.E, 1), H, dtype=torch.float32, device=dev)[: index.E]
         datt = torch.empty(index.E, dtype=torch.float32, device=dev) if need_att else None
+        tiles = None
+        if edge_emb is None and _FIXED_PNA.get((aggr_codes, scaler_codes)) and os.environ.get("GSAT_PNA_TILED", "1") != "0":
+            tiles = index.pna_tiles(H) or None
+        if tiles is not None:
+            # one launch: per-edge gradient rows stay in LDS and are summed per source there (no [E,H] round trip through HBM)
+            tile_ptr, T, rows_cap, edges_cap = tiles
+            dx = torch.empty_like(x)
+            spilled = torch.empty(max(index.E, 1), dtype=torch.uint8, device=dev)
+            call("gsat_pna_bwd_tiled", ptr(x), ptr(attf), ptr(dout), ptr(index.rowptr_dst), ptr(index.src_by_dst), ptr(index.eid_by_dst),
+                 ptr(tile_ptr), T, rows_cap, edges_cap, ptr(index.rowptr_src), ptr(index.slot_dst_of_srcslot), N, index.E, H,
+                 a_arr, A, s_arr, S, ptr(dx), ptr(dmsg), ptr(spilled), ptr(datt), stream())
+            return dx, (datt.view(ctx.att_shape) if need_att else None), None, None, None, None, None, None
+        dx_self = torch.empty_like(x)
         dee = torch.empty_like(edge_emb) if need_ee else None
         call("gsat_pna_bwd", ptr(x), ptr(attf), ptr(edge_emb), ptr(dout), ptr(index.rowptr_dst), ptr(index.src_by_dst),
              ptr(index.eid_by_dst), N, H, a_arr, A, s_arr, S, avg_lin, avg_log, ptr(dx_self), ptr(dmsg), ptr(datt),

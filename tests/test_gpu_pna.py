@@ -95,3 +95,54 @@ def test_pna_empty_rows_std(dev):
     out = pna_aggregate(x.to(dev), ix, None, None, ["mean", "min", "max", "std"], ["identity"], {"lin": 1.0, "log": 1.0}).cpu()
     assert torch.all(out[2:, : 3 * 2 * H] == 0)
     assert torch.allclose(out[2:, 3 * 2 * H:], torch.full((3, 2 * H), 1e-5 ** 0.5))
+
+
+@pytest.mark.parametrize("H", [16, 80, 128, 256])
+@pytest.mark.parametrize("lds_budget", [0, 6144])            # default windows / tiny windows: most edges spill, hub rows overflow the LDS edge capacity
+@pytest.mark.parametrize("aligned", [True, False])
+def test_pna_tiled_backward(dev, monkeypatch, H, lds_budget, aligned):
+    """The one-launch (LDS-resident) PNA backward vs the oracle and vs the two-pass backward: graph-aligned and fixed windows,
+    windows much smaller than the graphs (spilled edges), a hub row longer than a window's edge capacity, isolated nodes; bitwise
+    reproducible run to run."""
+    from dp_gsat_amd.graph_index import BatchIndex
+    from dp_gsat_amd.ops import pna_aggregate
+    monkeypatch.setenv("GSAT_PNA_TILE_LDS", str(lds_budget))
+    ei, batch, N = random_batch(11 + H, 24, 1, 40)
+    hub = torch.arange(1, 200)                                 # a star inside graph 0's id range is not block-diagonal: fine, tiles are windows
+    star = torch.stack([torch.cat([hub, torch.zeros_like(hub)]), torch.cat([torch.zeros_like(hub), hub])]) + (N - 200 if N > 400 else 0)
+    ei = shuffle_edges(torch.cat([ei, star.clamp_(max=N - 1)], dim=1), 2)
+    E = ei.shape[1]
+    g = torch.Generator().manual_seed(H)
+    x = torch.randn(N, H, generator=g)
+    x[::5] = x[::5].relu()
+    att = torch.rand(E, 1, generator=g)
+    aggr = ["mean", "min", "max", "std", "sum"] if H == 80 else ["mean", "min", "max", "std"]
+    avg = {"lin": 1.0, "log": 1.0}
+    go = torch.randn(N, len(aggr) * 2 * H, generator=g)
+    ref = {}
+    for dt in (torch.float32, torch.float64):
+        xo, ao = x.to(dt).clone().requires_grad_(True), att.to(dt).clone().requires_grad_(True)
+        oops.pna_aggregate(xo, ei, ao, aggr, ["identity"], avg).backward(go.to(dt))
+        ref[dt] = (xo.grad, ao.grad)
+
+    def run(tiled):
+        monkeypatch.setenv("GSAT_PNA_TILED", "1" if tiled else "0")
+        ix = BatchIndex(ei.to(dev), N)
+        if aligned:
+            ix.graphs(batch.to(dev))
+        if tiled:
+            tile_ptr, T, rows_cap, edges_cap = ix.pna_tiles(H)
+            tp = tile_ptr.cpu()
+            assert int(tp[0]) == 0 and int(tp[-1]) == N and bool((tp[1:] >= tp[:-1]).all()) and int((tp[1:] - tp[:-1]).max()) <= rows_cap
+        xd, ad = x.to(dev).requires_grad_(True), att.to(dev).requires_grad_(True)
+        pna_aggregate(xd, ix, ad, None, aggr, ["identity"], avg).backward(go.to(dev))
+        return xd.grad, ad.grad
+
+    dx, da = run(True)
+    close(dx, ref[torch.float32][0], ref64=ref[torch.float64][0], what="dx")
+    close(da, ref[torch.float32][1], ref64=ref[torch.float64][1], what="datt")
+    dx2, da2 = run(True)
+    assert torch.equal(dx, dx2) and torch.equal(da, da2)                      # bitwise reproducible
+    dx0, da0 = run(False)                                                      # the two-pass backward: same sums, other order
+    assert torch.equal(da, da0)
+    close(dx, dx0, 2e-6, what="dx tiled vs two-pass")
