@@ -385,39 +385,43 @@ __global__ __launch_bounds__(PNA_BLOCK, HAS_EE ? 2 : 4) void k_pna_bwd_dst(
 
 // ---- tiled backward: one workgroup owns a window of destination rows and their in-edges -------------------------------
 // The two-pass backward above writes every per-edge gradient row to HBM (dmsg [E,H]) and reads it back in the per-source sum:
-// 4*E*H*2 bytes of the step's traffic for nothing but a transpose.  Batched graphs are block-diagonal and molecule-sized, so a
-// window of TN consecutive rows (aligned to graph starts where a graph start is near, see k_pna_tiles) contains both endpoints
-// of nearly all of its edges.  One workgroup per window:
-//   phase 0  indices / attention of the window's edges -> LDS; the gathered x_j row of every edge -> LDS by LDS-DMA with a
-//            per-lane source address (all gathers of the window in flight at once, no per-row index -> row dependency chain)
-//   phase 1  a lane group per destination row: statistics and first-occurrence args from LDS, the upstream gradient row
-//            (64 % of the bytes) streamed into registers one row ahead, per-edge gradient row written IN PLACE over the
-//            gathered row in LDS; dx_self -> dx
-//   phase 2  a lane group per source row: dx[j] += its edges' rows in by-source slot order, straight from LDS
+// 8*E*H bytes of traffic for nothing but a transpose.  Batched graphs are block-diagonal and molecule-sized, so a window of
+// consecutive rows (aligned to graph starts where a graph start is near, see k_pna_tiles) contains both endpoints of nearly
+// all of its edges.  One workgroup per window, three dependent memory round trips in all:
+//   trip 1  the window descriptor (row / slot bounds of both CSRs)
+//   trip 2  the window's indices -> LDS, and each lane group's first upstream gradient row -> registers
+//   trip 3  the gathered x_j row of every edge -> LDS by LDS-DMA with a per-lane source address, and the attention of every edge
+//   rows    a lane group per destination row: statistics and first-occurrence args from LDS; as soon as the fold has consumed the
+//           gradient row the next one is requested into the same registers; the per-edge gradient row is written IN PLACE over
+//           the gathered row in LDS; dx_self -> dx
+//   sums    a lane group per source row: dx[j] += its edges' rows in by-source slot order, indices and rows straight from LDS
 // Edges whose source lies outside the window (or beyond the LDS edge capacity: hub rows) spill their row to dmsg and are
 // added by k_pna_bwd_spill afterwards, in by-source slot order as well, so the result is bitwise reproducible.
-constexpr int TILE_BLOCK = 256;
+constexpr int TILE_BLOCK = 512;
 
-__global__ void k_pna_tiles(const int32_t* __restrict__ node_ptr, const int32_t* __restrict__ node_seg, int N, int TN, int slack, int T,
-                            int32_t* __restrict__ tile_ptr) {
+// desc[t] = (first row of window t, rowptr_dst[row], rowptr_src[row], 0); desc[T] closes the last window
+__global__ void k_pna_tiles(const int32_t* __restrict__ node_ptr, const int32_t* __restrict__ node_seg, const int32_t* __restrict__ rowptr,
+                            const int32_t* __restrict__ rowptr_src, int N, int TN, int slack, int T, int4* __restrict__ desc) {
     const int t = blockIdx.x * blockDim.x + threadIdx.x;
     if (t > T) return;
     const int64_t p = (int64_t)t * TN;
-    if (t == T || p >= N) { tile_ptr[t] = N; return; }
-    int start = (int)p;
-    if (node_seg) {                 // pull the window start back to the start of the graph that contains row p, at most `slack` rows
-        const int g0 = node_ptr[node_seg[p]];
-        start = max(g0, (int)p - slack);
+    int start = N;
+    if (t < T && p < N) {
+        start = (int)p;
+        if (node_seg) {             // pull the window start back to the start of the graph that contains row p, at most `slack` rows
+            const int g0 = node_ptr[node_seg[p]];
+            start = max(g0, (int)p - slack);
+        }
     }
-    tile_ptr[t] = start;
+    desc[t] = make_int4(start, rowptr[start], rowptr_src[start], 0);
 }
 
 template <int LPR, int NAGG>
-__global__ __launch_bounds__(TILE_BLOCK) void k_pna_bwd_tile(
+__global__ __launch_bounds__(TILE_BLOCK, 4) void k_pna_bwd_tile(
     const float* __restrict__ x, const float* __restrict__ att, const float* __restrict__ dout, const int32_t* __restrict__ rowptr,
-    const int32_t* __restrict__ col, const int32_t* __restrict__ eid, const int32_t* __restrict__ tile_ptr,
+    const int32_t* __restrict__ col, const int32_t* __restrict__ eid, const int4* __restrict__ desc,
     const int32_t* __restrict__ rowptr_src, const int32_t* __restrict__ slot_map, int H, int TE, int RCAP, float* dx,
-    float* __restrict__ dmsg, uint8_t* __restrict__ spilled, float* __restrict__ datt) {
+    float* __restrict__ dmsg, float* __restrict__ datt) {
     constexpr int GPB = TILE_BLOCK / LPR;        // lane groups (rows in flight) per workgroup
     constexpr int RPW = 64 / LPR;                // rows covered by one wave-instruction
     constexpr int NSEG = NAGG * 2;
@@ -426,34 +430,22 @@ __global__ __launch_bounds__(TILE_BLOCK) void k_pna_bwd_tile(
     int* s_col = reinterpret_cast<int*>(erow + (size_t)TE * LPR);
     int* s_eid = s_col + TE;
     float* s_att = reinterpret_cast<float*>(s_eid + TE);
-    int* s_rp = reinterpret_cast<int*>(s_att + TE);              // [RCAP+1] row pointers relative to the window's first slot
-    const int tid = threadIdx.x, wave = tid >> 6, lw = tid & 63;
+    int* s_slot = reinterpret_cast<int*>(s_att + TE);            // [TE] by-source slots of the window's sources -> window-local by-destination slot
+    int* s_rp = s_slot + TE;                                     // [RCAP+1] by-destination row pointers relative to the window's first slot
+    int* s_rps = s_rp + RCAP + 1;                                // [RCAP+1] by-source row pointers relative to the window's first slot
+    const int tid = threadIdx.x, wave = tid >> 6;
     const int grp = tid / LPR, lane = tid % LPR, c = lane * 4;
     const bool on = c < H;
     const int t = pna_xcd_remap(blockIdx.x, gridDim.x);
-    const int n0 = tile_ptr[t], n1 = tile_ptr[t + 1];
+    const int4 d0 = desc[t], d1 = desc[t + 1];
+    const int n0 = d0.x, n1 = d1.x;
     if (n1 <= n0) return;
-    const int nr = n1 - n0;                                      // <= RCAP by construction of the tiles
-    const int k0 = rowptr[n0], k1 = rowptr[n1];
-    const int ne = min(k1 - k0, TE);
-    // ---- phase 0: indices, then every gathered row of the window in flight at once -------------------
-    for (int i = tid; i <= nr; i += TILE_BLOCK) s_rp[i] = rowptr[n0 + i] - k0;
-    for (int i = tid; i < ne; i += TILE_BLOCK) {
-        const int e = eid[k0 + i];
-        s_col[i] = col[k0 + i];
-        s_eid[i] = e;
-        s_att[i] = att ? att[e] : 1.f;
-    }
-    __syncthreads();
-    for (int base = 0; base < ne; base += GPB) {
-        const int i = base + grp;
-        if (i < ne && on)
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(x + (size_t)s_col[i] * H + c),
-                                             (__attribute__((address_space(3))) void*)(erow + (size_t)(base + wave * RPW) * LPR), 16, 0, 0);
-    }
-    // the upstream gradient row of this lane group's first row joins the same burst
-    float4 dcur[NSEG], dnx[NSEG];
-    float4 xi_cur = f4zero(), xi_nx = f4zero();
+    const int nr = n1 - n0;                                      // <= RCAP by construction of the windows
+    const int k0 = d0.y, ne = min(d1.y - k0, TE);
+    const int s0 = d0.z, ns = d1.z - s0, nsl = min(ns, TE);
+    // ---- trip 2 ------------------------------------------------------------------------------------------
+    float4 dcur[NSEG];
+    float4 xi_cur = f4zero();
     const size_t out_stride = (size_t)NSEG * H;
     int row = n0 + grp;
 #pragma unroll
@@ -464,136 +456,147 @@ __global__ __launch_bounds__(TILE_BLOCK) void k_pna_bwd_tile(
         for (int sg = 0; sg < NSEG; ++sg) dcur[sg] = ld4(g0 + (size_t)sg * H);
         xi_cur = ld4(x + (size_t)row * H + c);
     }
+    for (int i = tid; i <= nr; i += TILE_BLOCK) {
+        s_rp[i] = rowptr[n0 + i] - k0;
+        s_rps[i] = rowptr_src[n0 + i] - s0;
+    }
+    for (int i = tid; i < ne; i += TILE_BLOCK) {
+        s_col[i] = col[k0 + i];
+        s_eid[i] = eid[k0 + i];
+    }
+    for (int i = tid; i < nsl; i += TILE_BLOCK) s_slot[i] = slot_map[s0 + i] - k0;
+    __syncthreads();
+    // ---- trip 3 ------------------------------------------------------------------------------------------
+    for (int base = 0; base < ne; base += GPB) {
+        const int i = base + grp;
+        if (i < ne && on)
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(x + (size_t)s_col[i] * H + c),
+                                             (__attribute__((address_space(3))) void*)(erow + (size_t)(base + wave * RPW) * LPR), 16, 0, 0);
+    }
+    for (int i = tid; i < ne; i += TILE_BLOCK) s_att[i] = att ? att[s_eid[i]] : 1.f;
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
-    // ---- phase 1: destination rows ----------------------------------------------------------------------
+    // ---- destination rows ----------------------------------------------------------------------------------
     for (; row < n1; row += GPB) {
         const int nrow = row + GPB;
-        if (nrow < n1 && on) {                                   // next row's gradient: in flight under this row's arithmetic
-            const float* g0 = dout + (size_t)nrow * out_stride + c;
-#pragma unroll
-            for (int sg = 0; sg < NSEG; ++sg) dnx[sg] = ld4(g0 + (size_t)sg * H);
-            xi_nx = ld4(x + (size_t)nrow * H + c);
-        } else {
-#pragma unroll
-            for (int sg = 0; sg < NSEG; ++sg) dnx[sg] = f4zero();
-        }
         const int beg = s_rp[row - n0], end = s_rp[row - n0 + 1];
         const float cnt = (float)(end - beg);
-        if (end == beg) {
-            if (on) st4(dx + (size_t)row * H + c, f4zero());
-        } else {
-            // pass 1: statistics and first-occurrence args
-            float sa = 0.f, sa2 = 0.f, amin = INFINITY, amax = -INFINITY;
-            int kmin_a = beg, kmax_a = beg;
-            Acc4 aj;
-            aj.init();
-            int4 jmin = make_int4(beg, beg, beg, beg), jmax = jmin;
-            float wfirst = 1.f;
-            for (int k = beg; k < end; ++k) {
-                float w;
-                float4 xv;
-                if (k < ne) {
-                    w = s_att[k];
-                    xv = on ? erow[(size_t)k * LPR + lane] : f4zero();
-                } else {                                         // beyond the LDS edge capacity (hub rows): straight from memory
-                    w = att ? att[eid[k0 + k]] : 1.f;
-                    xv = on ? ld4(x + (size_t)col[k0 + k] * H + c) : f4zero();
-                }
-                if (k == beg) wfirst = w;
-                sa += w; sa2 = fmaf(w, w, sa2);
-                if (w < amin) { amin = w; kmin_a = k; }
-                if (w > amax) { amax = w; kmax_a = k; }
-                const float4 m = f4scale(w, xv);
-                if (m.x < aj.mn.x) jmin.x = k; if (m.y < aj.mn.y) jmin.y = k; if (m.z < aj.mn.z) jmin.z = k; if (m.w < aj.mn.w) jmin.w = k;
-                if (m.x > aj.mx.x) jmax.x = k; if (m.y > aj.mx.y) jmax.y = k; if (m.z > aj.mx.z) jmax.z = k; if (m.w > aj.mx.w) jmax.w = k;
-                aj.add(m);
+        // pass 1: statistics and first-occurrence args (empty rows fall through with zero statistics)
+        float sa = 0.f, sa2 = 0.f, amin = INFINITY, amax = -INFINITY;
+        int kmin_a = beg, kmax_a = beg;
+        Acc4 aj;
+        aj.init();
+        int4 jmin = make_int4(beg, beg, beg, beg), jmax = jmin;
+        float wfirst = 1.f;
+        for (int k = beg; k < end; ++k) {
+            float w;
+            float4 xv;
+            if (k < ne) {
+                w = s_att[k];
+                xv = on ? erow[(size_t)k * LPR + lane] : f4zero();
+            } else {                                             // beyond the LDS edge capacity (hub rows): straight from memory
+                w = att ? att[eid[k0 + k]] : 1.f;
+                xv = on ? ld4(x + (size_t)col[k0 + k] * H + c) : f4zero();
             }
-            const Acc4 ai = self_stats(xi_cur, sa, sa2, amin, amax);
-            const float n = fmaxf(cnt, 1.f), inv_n = 1.f / n;
-            float t1 = 0.f, t2 = 0.f, tmn = 0.f, tmx = 0.f;
-            float4 Pi, Qi, Pj, Qj, gmn_i, gmx_i, gmn_j, gmx_j;
-#define GSAT_TFOLD(ACC, PART, P, Q, GMN, GMX)                                                                          \
-            {                                                                                                          \
-                const float4 mean = f4scale(inv_n, ACC.s);                                                             \
-                const float4 var = make_float4(ACC.q.x * inv_n - mean.x * mean.x, ACC.q.y * inv_n - mean.y * mean.y,   \
-                                               ACC.q.z * inv_n - mean.z * mean.z, ACC.q.w * inv_n - mean.w * mean.w);  \
-                const float4 hs = make_float4(var.x > 0.f ? 0.5f / sqrtf(var.x + 1e-5f) : 0.f, var.y > 0.f ? 0.5f / sqrtf(var.y + 1e-5f) : 0.f, \
-                                              var.z > 0.f ? 0.5f / sqrtf(var.z + 1e-5f) : 0.f, var.w > 0.f ? 0.5f / sqrtf(var.w + 1e-5f) : 0.f); \
-                float4 p0 = f4scale(inv_n, dcur[0 * 2 + (PART)]);                                                      \
-                if (NAGG == 5) { const float4 vsum = dcur[(NAGG == 5 ? 4 : 0) * 2 + (PART)];                           \
-                                 p0 = make_float4(p0.x + vsum.x, p0.y + vsum.y, p0.z + vsum.z, p0.w + vsum.w); }       \
-                GMN = dcur[1 * 2 + (PART)];                                                                            \
-                GMX = dcur[2 * 2 + (PART)];                                                                            \
-                const float4 vs = dcur[3 * 2 + (PART)];                                                                \
-                const float4 gv = make_float4(vs.x * hs.x, vs.y * hs.y, vs.z * hs.z, vs.w * hs.w);                     \
-                Q = f4scale(2.f * inv_n, gv);                                                                          \
-                P = make_float4(p0.x - mean.x * Q.x, p0.y - mean.y * Q.y, p0.z - mean.z * Q.z, p0.w - mean.w * Q.w);   \
-            }
-            GSAT_TFOLD(ai, 0, Pi, Qi, gmn_i, gmx_i)
-            GSAT_TFOLD(aj, 1, Pj, Qj, gmn_j, gmx_j)
+            if (k == beg) wfirst = w;
+            sa += w; sa2 = fmaf(w, w, sa2);
+            if (w < amin) { amin = w; kmin_a = k; }
+            if (w > amax) { amax = w; kmax_a = k; }
+            const float4 m = f4scale(w, xv);
+            if (m.x < aj.mn.x) jmin.x = k; if (m.y < aj.mn.y) jmin.y = k; if (m.z < aj.mn.z) jmin.z = k; if (m.w < aj.mn.w) jmin.w = k;
+            if (m.x > aj.mx.x) jmax.x = k; if (m.y > aj.mx.y) jmax.y = k; if (m.z > aj.mx.z) jmax.z = k; if (m.w > aj.mx.w) jmax.w = k;
+            aj.add(m);
+        }
+        const float4 xi = xi_cur;
+        const Acc4 ai = self_stats(xi, sa, sa2, amin, amax);
+        const float n = fmaxf(cnt, 1.f), inv_n = 1.f / n;
+        float t1 = 0.f, t2 = 0.f, tmn = 0.f, tmx = 0.f;
+        float4 Pi, Qi, Pj, Qj, gmn_i, gmx_i, gmn_j, gmx_j;
+#define GSAT_TFOLD(ACC, PART, P, Q, GMN, GMX)                                                                              \
+        {                                                                                                                  \
+            const float4 mean = f4scale(inv_n, ACC.s);                                                                     \
+            const float4 var = make_float4(ACC.q.x * inv_n - mean.x * mean.x, ACC.q.y * inv_n - mean.y * mean.y,           \
+                                           ACC.q.z * inv_n - mean.z * mean.z, ACC.q.w * inv_n - mean.w * mean.w);          \
+            const float4 hs = make_float4(var.x > 0.f ? 0.5f * __builtin_amdgcn_rsqf(var.x + 1e-5f) : 0.f,                 \
+                                          var.y > 0.f ? 0.5f * __builtin_amdgcn_rsqf(var.y + 1e-5f) : 0.f,                 \
+                                          var.z > 0.f ? 0.5f * __builtin_amdgcn_rsqf(var.z + 1e-5f) : 0.f,                 \
+                                          var.w > 0.f ? 0.5f * __builtin_amdgcn_rsqf(var.w + 1e-5f) : 0.f);                \
+            float4 p0 = f4scale(inv_n, dcur[0 * 2 + (PART)]);                                                              \
+            if (NAGG == 5) { const float4 vsum = dcur[(NAGG == 5 ? 4 : 0) * 2 + (PART)];                                   \
+                             p0 = make_float4(p0.x + vsum.x, p0.y + vsum.y, p0.z + vsum.z, p0.w + vsum.w); }               \
+            GMN = dcur[1 * 2 + (PART)];                                                                                    \
+            GMX = dcur[2 * 2 + (PART)];                                                                                    \
+            const float4 vs = dcur[3 * 2 + (PART)];                                                                        \
+            const float4 gv = make_float4(vs.x * hs.x, vs.y * hs.y, vs.z * hs.z, vs.w * hs.w);                             \
+            Q = f4scale(2.f * inv_n, gv);                                                                                  \
+            P = make_float4(p0.x - mean.x * Q.x, p0.y - mean.y * Q.y, p0.z - mean.z * Q.z, p0.w - mean.w * Q.w);           \
+        }
+        GSAT_TFOLD(ai, 0, Pi, Qi, gmn_i, gmx_i)
+        GSAT_TFOLD(aj, 1, Pj, Qj, gmn_j, gmx_j)
 #undef GSAT_TFOLD
-            if (on) {      // x_i third in closed form (see k_pna_bwd_dst)
-                const float4 xi = xi_cur;
-                float4 dxi;
-#define GSAT_TSELF(C)                                                                                                  \
-                {                                                                                                      \
-                    const float xc = xi.C;                                                                             \
-                    const float wlo = xc > 0.f ? amin : (xc < 0.f ? amax : wfirst), whi = xc > 0.f ? amax : (xc < 0.f ? amin : wfirst); \
-                    dxi.C = Pi.C * sa + Qi.C * xc * sa2 + gmn_i.C * wlo + gmx_i.C * whi;                               \
-                    t1 = fmaf(Pi.C, xc, t1);                                                                           \
-                    t2 = fmaf(Qi.C * xc, xc, t2);                                                                      \
-                    tmn += xc > 0.f ? gmn_i.C * xc : (xc < 0.f ? gmx_i.C * xc : 0.f);                                  \
-                    tmx += xc > 0.f ? gmx_i.C * xc : (xc < 0.f ? gmn_i.C * xc : 0.f);                                  \
-                }
-                GSAT_TSELF(x) GSAT_TSELF(y) GSAT_TSELF(z) GSAT_TSELF(w)
-#undef GSAT_TSELF
-                st4(dx + (size_t)row * H + c, dxi);
+        // the gradient row is consumed: request the next one into the same registers, in flight under the rest of this row
+        if (nrow < n1 && on) {
+            const float* g0 = dout + (size_t)nrow * out_stride + c;
+#pragma unroll
+            for (int sg = 0; sg < NSEG; ++sg) dcur[sg] = ld4(g0 + (size_t)sg * H);
+            xi_cur = ld4(x + (size_t)nrow * H + c);
+        }
+        if (on) {      // x_i third in closed form (see k_pna_bwd_dst); an empty row gets exact zeros (P = Q = 0 * finite, sums 0)
+            float4 dxi;
+#define GSAT_TSELF(C)                                                                                                      \
+            {                                                                                                              \
+                const float xc = xi.C;                                                                                     \
+                const float wlo = xc > 0.f ? amin : (xc < 0.f ? amax : wfirst), whi = xc > 0.f ? amax : (xc < 0.f ? amin : wfirst); \
+                dxi.C = Pi.C * sa + Qi.C * xc * sa2 + gmn_i.C * wlo + gmx_i.C * whi;                                       \
+                t1 = fmaf(Pi.C, xc, t1);                                                                                   \
+                t2 = fmaf(Qi.C * xc, xc, t2);                                                                              \
+                tmn += xc > 0.f ? gmn_i.C * xc : (xc < 0.f ? gmx_i.C * xc : 0.f);                                          \
+                tmx += xc > 0.f ? gmx_i.C * xc : (xc < 0.f ? gmn_i.C * xc : 0.f);                                          \
             }
-            // pass 2: per-edge gradient rows, in place over the gathered rows
-            for (int k = beg; k < end; ++k) {
-                float w;
-                float4 xj;
-                int e, j;
-                if (k < ne) {
-                    w = s_att[k]; e = s_eid[k]; j = s_col[k];
-                    xj = on ? erow[(size_t)k * LPR + lane] : f4zero();
-                } else {
-                    e = eid[k0 + k]; j = col[k0 + k];
-                    w = att ? att[e] : 1.f;
-                    xj = on ? ld4(x + (size_t)j * H + c) : f4zero();
-                }
-                const bool in_lds = k < ne && j >= n0 && j < n1;
-                float da = 0.f;
-                if (on) {
-                    float4 dm;
-                    dm.x = fmaf(Qj.x, w * xj.x, Pj.x) + (k == jmin.x ? gmn_j.x : 0.f) + (k == jmax.x ? gmx_j.x : 0.f);
-                    dm.y = fmaf(Qj.y, w * xj.y, Pj.y) + (k == jmin.y ? gmn_j.y : 0.f) + (k == jmax.y ? gmx_j.y : 0.f);
-                    dm.z = fmaf(Qj.z, w * xj.z, Pj.z) + (k == jmin.z ? gmn_j.z : 0.f) + (k == jmax.z ? gmx_j.z : 0.f);
-                    dm.w = fmaf(Qj.w, w * xj.w, Pj.w) + (k == jmin.w ? gmn_j.w : 0.f) + (k == jmax.w ? gmx_j.w : 0.f);
-                    const float4 o = f4scale(w, dm);
-                    if (in_lds) erow[(size_t)k * LPR + lane] = o; else st4(dmsg + (size_t)(k0 + k) * H + c, o);
-                    da = f4dot(dm, xj) + t1 + w * t2 + (k == kmin_a ? tmn : 0.f) + (k == kmax_a ? tmx : 0.f);
-                }
-                if (lane == 0) spilled[k0 + k] = in_lds ? 0 : 1;
-                if (datt) {
-                    da = group_sum<LPR>(da);
-                    if (lane == 0) datt[e] = da;
-                }
+            GSAT_TSELF(x) GSAT_TSELF(y) GSAT_TSELF(z) GSAT_TSELF(w)
+#undef GSAT_TSELF
+            if (end == beg) dxi = f4zero();                      // amin/amax are +-inf on an empty row: no in-edges, no gradient
+            st4(dx + (size_t)row * H + c, dxi);
+        }
+        // pass 2: per-edge gradient rows, in place over the gathered rows
+        for (int k = beg; k < end; ++k) {
+            float w;
+            float4 xj;
+            int e, j;
+            if (k < ne) {
+                w = s_att[k]; e = s_eid[k]; j = s_col[k];
+                xj = on ? erow[(size_t)k * LPR + lane] : f4zero();
+            } else {
+                e = eid[k0 + k]; j = col[k0 + k];
+                w = att ? att[e] : 1.f;
+                xj = on ? ld4(x + (size_t)j * H + c) : f4zero();
+            }
+            const bool in_lds = k < ne && j >= n0 && j < n1;
+            float da = 0.f;
+            if (on) {
+                float4 dm;
+                dm.x = fmaf(Qj.x, w * xj.x, Pj.x) + (k == jmin.x ? gmn_j.x : 0.f) + (k == jmax.x ? gmx_j.x : 0.f);
+                dm.y = fmaf(Qj.y, w * xj.y, Pj.y) + (k == jmin.y ? gmn_j.y : 0.f) + (k == jmax.y ? gmx_j.y : 0.f);
+                dm.z = fmaf(Qj.z, w * xj.z, Pj.z) + (k == jmin.z ? gmn_j.z : 0.f) + (k == jmax.z ? gmx_j.z : 0.f);
+                dm.w = fmaf(Qj.w, w * xj.w, Pj.w) + (k == jmin.w ? gmn_j.w : 0.f) + (k == jmax.w ? gmx_j.w : 0.f);
+                const float4 o = f4scale(w, dm);
+                if (in_lds) erow[(size_t)k * LPR + lane] = o; else st4(dmsg + (size_t)(k0 + k) * H + c, o);
+                da = f4dot(dm, xj) + t1 + w * t2 + (k == kmin_a ? tmn : 0.f) + (k == kmax_a ? tmx : 0.f);
+            }
+            if (datt) {
+                da = group_sum<LPR>(da);
+                if (lane == 0) datt[e] = da;
             }
         }
-#pragma unroll
-        for (int sg = 0; sg < NSEG; ++sg) dcur[sg] = dnx[sg];
-        xi_cur = xi_nx;
     }
     __syncthreads();
-    // ---- phase 2: per-source sums over the rows kept in LDS (same lane group <-> row map as phase 1: dx[j] is this thread's own) ----
+    // ---- per-source sums over the rows kept in LDS (same lane group <-> row map as above: dx[j] is this thread's own store) ----
     for (int j = n0 + grp; j < n1; j += GPB) {
         if (!on) continue;
-        const int sb = rowptr_src[j], se = rowptr_src[j + 1];
+        const int sb = s_rps[j - n0], se = s_rps[j - n0 + 1];
         float4 acc = ld4(dx + (size_t)j * H + c);
         for (int s_ = sb; s_ < se; ++s_) {
-            const int kl = slot_map[s_] - k0;
+            const int kl = s_ < nsl ? s_slot[s_] : slot_map[s0 + s_] - k0;
             if (kl >= 0 && kl < ne) {
                 const float4 v = erow[(size_t)kl * LPR + lane];
                 acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
@@ -603,21 +606,27 @@ __global__ __launch_bounds__(TILE_BLOCK) void k_pna_bwd_tile(
     }
 }
 
-// dx[j] += the spilled rows of source j, by-source slot order (rows whose edges all stayed in LDS are not touched)
+// dx[j] += the rows of source j that k_pna_bwd_tile spilled to dmsg, in by-source slot order (rows whose edges all stayed in LDS
+// are not touched).  An edge stayed in LDS iff its by-destination slot lies among the first TE slots of its SOURCE's window.
 template <int LPR>
-__global__ __launch_bounds__(TILE_BLOCK) void k_pna_bwd_spill(const float* __restrict__ dmsg, const uint8_t* __restrict__ spilled,
-                                                             const int32_t* __restrict__ rowptr_src, const int32_t* __restrict__ slot_map,
-                                                             int num_rows, int H, float* __restrict__ dx) {
+__global__ __launch_bounds__(TILE_BLOCK) void k_pna_bwd_spill(const float* __restrict__ dmsg, const int4* __restrict__ desc, int TN, int TE,
+                                                             const int32_t* __restrict__ rowptr_src,
+                                                             const int32_t* __restrict__ slot_map, int num_rows, int H, float* __restrict__ dx) {
     constexpr int GPB = TILE_BLOCK / LPR;
     const int lane = threadIdx.x % LPR, c = lane * 4;
     if (c >= H) return;
     for (int j = blockIdx.x * GPB + threadIdx.x / LPR; j < num_rows; j += gridDim.x * GPB) {
         const int sb = rowptr_src[j], se = rowptr_src[j + 1];
+        if (sb == se) continue;
+        int t = j / TN;                                   // window starts are pulled back by at most TN rows: j is in window t or t + 1
+        if (j >= desc[t + 1].x) ++t;
+        const int k0 = desc[t].y;
+        const int ne = min(desc[t + 1].y - k0, TE);
         bool any = false;
         float4 acc = f4zero();
         for (int s_ = sb; s_ < se; ++s_) {
             const int k = slot_map[s_];
-            if (!spilled[k]) continue;
+            if (k >= k0 && k < k0 + ne) continue;
             if (!any) { acc = ld4(dx + (size_t)j * H + c); any = true; }
             const float4 v = ld4(dmsg + (size_t)k * H + c);
             acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
@@ -674,7 +683,7 @@ static hipError_t pna_tile_allow_lds(size_t lds) {       // raise the kernel's d
 }
 
 static size_t pna_tile_lds_bytes(int lpr, int edges_cap, int rows_cap) {
-    return (size_t)edges_cap * ((size_t)lpr * 16 + 12) + (size_t)(rows_cap + 1) * 4;
+    return (size_t)edges_cap * ((size_t)lpr * 16 + 16) + (size_t)(rows_cap + 1) * 8;
 }
 
 }  // namespace gsat
@@ -748,9 +757,9 @@ int gsat_pna_tile_plan(int64_t H, int64_t lds_budget_bytes, int32_t* rows_nomina
     const int lpr = pna_lpr(H);
     GSAT_REQUIRE(lpr, GSAT_ERR_UNSUPPORTED, "gsat_pna_tile_plan: H=%lld must be a multiple of 4 and <= 256", (long long)H);
     GSAT_REQUIRE(rows_nominal && rows_slack && edges_cap, GSAT_ERR_ARG, "gsat_pna_tile_plan: null pointer");
-    if (lds_budget_bytes <= 0) lds_budget_bytes = 48 * 1024;
+    if (lds_budget_bytes <= 0) lds_budget_bytes = 80 * 1024;      // one workgroup per CU: measured best at C3 (profiles/r02_pna_bwd_probe.txt)
     GSAT_REQUIRE(lds_budget_bytes <= 160 * 1024, GSAT_ERR_ARG, "gsat_pna_tile_plan: LDS budget above 160 KiB");
-    int64_t te = (lds_budget_bytes - 1024) / ((int64_t)lpr * 16 + 12);
+    int64_t te = (lds_budget_bytes - 1024) / ((int64_t)lpr * 16 + 16);
     te = te / 8 * 8;
     GSAT_REQUIRE(te >= 16, GSAT_ERR_UNSUPPORTED, "gsat_pna_tile_plan: LDS budget too small for H=%lld", (long long)H);
     int64_t half = std::max<int64_t>(4, te / 4 / 4 * 4);        // window = [nominal, nominal + slack] rows, ~2 in-edges per row
@@ -760,22 +769,25 @@ int gsat_pna_tile_plan(int64_t H, int64_t lds_budget_bytes, int32_t* rows_nomina
     return GSAT_OK;
 }
 
-int gsat_pna_build_tiles(const int32_t* node_ptr, const int32_t* node_seg, int64_t N, int rows_nominal, int rows_slack,
-                         int32_t* tile_ptr, void* stream_) {
+int gsat_pna_build_tiles(const int32_t* node_ptr, const int32_t* node_seg, const int32_t* rowptr, const int32_t* rowptr_src, int64_t N,
+                         int rows_nominal, int rows_slack, int32_t* tile_desc, void* stream_) {
     hipStream_t stream = (hipStream_t)stream_;
-    GSAT_REQUIRE(N >= 0 && N < (1ll << 31) && rows_nominal > 0 && rows_slack >= 0 && tile_ptr, GSAT_ERR_ARG, "gsat_pna_build_tiles: bad argument");
+    GSAT_REQUIRE(N >= 0 && N < (1ll << 31) && rows_nominal > 0 && rows_slack >= 0 && rows_slack <= rows_nominal && tile_desc && rowptr && rowptr_src,
+                 GSAT_ERR_ARG, "gsat_pna_build_tiles: bad argument");
+    GSAT_REQUIRE(((uintptr_t)tile_desc & 15) == 0, GSAT_ERR_ARG, "gsat_pna_build_tiles: tile_desc must be 16-byte aligned");
     GSAT_REQUIRE((node_ptr == nullptr) == (node_seg == nullptr), GSAT_ERR_ARG, "gsat_pna_build_tiles: node_ptr and node_seg go together");
     const int64_t T = ceil_div(N, rows_nominal);
-    k_pna_tiles<<<(int)ceil_div(T + 1, 256), 256, 0, stream>>>(node_ptr, node_seg, (int)N, rows_nominal, node_seg ? rows_slack : 0, (int)T, tile_ptr);
+    k_pna_tiles<<<(int)ceil_div(T + 1, 256), 256, 0, stream>>>(node_ptr, node_seg, rowptr, rowptr_src, (int)N, rows_nominal, node_seg ? rows_slack : 0, (int)T,
+                                                               (int4*)tile_desc);
     GSAT_LAUNCH_CHECK();
     return GSAT_OK;
 }
 
 int gsat_pna_bwd_tiled(const float* x, const float* att, const float* dout, const int32_t* rowptr, const int32_t* col,
-                       const int32_t* eid, const int32_t* tile_ptr, int64_t num_tiles, int rows_cap, int edges_cap,
+                       const int32_t* eid, const int32_t* tile_desc, int64_t num_tiles, int rows_nominal, int rows_cap, int edges_cap,
                        const int32_t* rowptr_src, const int32_t* slot_dst_of_srcslot, int64_t N, int64_t E, int64_t H,
-                       const int32_t* aggregators, int A, const int32_t* scalers, int S, float* dx, float* dmsg, uint8_t* spilled,
-                       float* datt, void* stream_) {
+                       const int32_t* aggregators, int A, const int32_t* scalers, int S, float* dx, float* dmsg, float* datt,
+                       void* stream_) {
     hipStream_t stream = (hipStream_t)stream_;
     GSAT_REQUIRE(N >= 0 && N < (1ll << 31) && E >= 0 && num_tiles >= 0, GSAT_ERR_ARG, "gsat_pna_bwd_tiled: bad extents");
     PnaCfg cfg;
@@ -786,15 +798,15 @@ int gsat_pna_bwd_tiled(const float* x, const float* att, const float* dout, cons
     if (N == 0) return GSAT_OK;
     const int lpr = pna_lpr(H);
     GSAT_REQUIRE(lpr, GSAT_ERR_UNSUPPORTED, "gsat_pna_bwd_tiled: H=%lld must be a multiple of 4 and <= 256", (long long)H);
-    GSAT_REQUIRE(x && dout && rowptr && tile_ptr && rowptr_src && dx && rows_cap > 0 && edges_cap > 0, GSAT_ERR_ARG, "gsat_pna_bwd_tiled: null pointer");
-    GSAT_REQUIRE(E == 0 || (col && eid && slot_dst_of_srcslot && dmsg && spilled), GSAT_ERR_ARG, "gsat_pna_bwd_tiled: null edge arrays");
+    GSAT_REQUIRE(x && dout && rowptr && tile_desc && rowptr_src && dx && rows_nominal > 0 && rows_cap >= rows_nominal && rows_cap <= 2 * rows_nominal && edges_cap > 0, GSAT_ERR_ARG, "gsat_pna_bwd_tiled: null pointer");
+    GSAT_REQUIRE(E == 0 || (col && eid && slot_dst_of_srcslot && dmsg), GSAT_ERR_ARG, "gsat_pna_bwd_tiled: null edge arrays");
     const size_t lds = pna_tile_lds_bytes(lpr, edges_cap, rows_cap);
     GSAT_REQUIRE(lds <= 160 * 1024, GSAT_ERR_ARG, "gsat_pna_bwd_tiled: tile needs %zu bytes of LDS", lds);
 #define GO(L, NA)                                                                                                            \
     do {                                                                                                                     \
         GSAT_CHECK_HIP((pna_tile_allow_lds<L, NA>(lds)));                                                                    \
-        k_pna_bwd_tile<L, NA><<<(int)num_tiles, TILE_BLOCK, lds, stream>>>(x, att, dout, rowptr, col, eid, tile_ptr, rowptr_src, \
-                                                                          slot_dst_of_srcslot, (int)H, edges_cap, rows_cap, dx, dmsg, spilled, datt); \
+        k_pna_bwd_tile<L, NA><<<(int)num_tiles, TILE_BLOCK, lds, stream>>>(x, att, dout, rowptr, col, eid, (const int4*)tile_desc,     \
+                                                                          rowptr_src, slot_dst_of_srcslot, (int)H, edges_cap, rows_cap, dx, dmsg, datt); \
     } while (0)
 #define CALL(L) do { if (nagg == 4) GO(L, 4); else GO(L, 5); } while (0)
     if (num_tiles > 0) { GSAT_LPR_DISPATCH(lpr, CALL); }
@@ -804,7 +816,7 @@ int gsat_pna_bwd_tiled(const float* x, const float* att, const float* dout, cons
     if (E > 0) {
         const int gpb = TILE_BLOCK / lpr;
         const int nb = (int)std::min<int64_t>(ceil_div(N, gpb), 256 * 16);
-#define CALL(L) k_pna_bwd_spill<L><<<nb, TILE_BLOCK, 0, stream>>>(dmsg, spilled, rowptr_src, slot_dst_of_srcslot, (int)N, (int)H, dx)
+#define CALL(L) k_pna_bwd_spill<L><<<nb, TILE_BLOCK, 0, stream>>>(dmsg, (const int4*)tile_desc, rows_nominal, edges_cap, rowptr_src, slot_dst_of_srcslot, (int)N, (int)H, dx)
         GSAT_LPR_DISPATCH(lpr, CALL);
 #undef CALL
         GSAT_LAUNCH_CHECK();

@@ -200,24 +200,25 @@ int gsat_pna_bwd(const float* x, const float* att, const float* edge_emb, const 
  * Tiled backward for the reference's aggregator lists (mean,min,max,std[,sum]; identity scaler; no edge_attr third): one
  * launch writes dx directly.  A workgroup owns a window ("tile") of consecutive destination rows and their in-edges; the
  * per-edge gradient rows stay in LDS and are summed per source there, so dmsg [E,H] is only touched by edges whose source lies
- * outside the window ("spilled", flagged per by-destination slot in `spilled`); a second small launch adds those.  Summation
+ * outside the window ("spilled"); a second small launch adds those.  Summation
  * order per source: dx_self, in-window rows in by-source slot order, spilled rows in by-source slot order (bitwise reproducible).
- *   gsat_pna_tile_plan:   window geometry for width H and an LDS budget per workgroup (0 -> 48 KiB): windows span
+ *   gsat_pna_tile_plan:   window geometry for width H and an LDS budget per workgroup (0 -> 80 KiB): windows span
  *                         rows_nominal .. rows_nominal + rows_slack rows and hold edges_cap in-edges in LDS.
- *   gsat_pna_build_tiles: tile_ptr int32[T+1], T = ceil(N / rows_nominal); window t starts at max(start of the graph containing row
+ *   gsat_pna_build_tiles: tile_desc int32[T+1][4] (16-byte aligned) = (first row, rowptr[row], rowptr_src[row], 0) of every window,
+ *                         T = ceil(N / rows_nominal); window t starts at max(start of the graph containing row
  *                         t*rows_nominal, t*rows_nominal - rows_slack) when node_ptr [G+1] / node_seg [N] (gsat_segment_ptr32) are
  *                         given -- block-diagonal batches then lose almost no edge to a window boundary -- else at t*rows_nominal.
- *   gsat_pna_bwd_tiled:   rows_cap >= the longest window (rows_nominal + rows_slack); dmsg [E,H] and spilled uint8[E] are scratch.
+ *   gsat_pna_bwd_tiled:   rows_cap >= the longest window (rows_nominal + rows_slack <= 2 rows_nominal); dmsg [E,H] is scratch.
  * replaces: autograd backward of PNAConvSimple.message/aggregate (src/models/conv_layers.py:166-185).
  */
 int gsat_pna_tile_plan(int64_t H, int64_t lds_budget_bytes, int32_t* rows_nominal, int32_t* rows_slack, int32_t* edges_cap);
-int gsat_pna_build_tiles(const int32_t* node_ptr, const int32_t* node_seg, int64_t num_rows, int rows_nominal, int rows_slack,
-                         int32_t* tile_ptr, void* stream);
+int gsat_pna_build_tiles(const int32_t* node_ptr, const int32_t* node_seg, const int32_t* rowptr, const int32_t* rowptr_src,
+                         int64_t num_rows, int rows_nominal, int rows_slack, int32_t* tile_desc, void* stream);
 int gsat_pna_bwd_tiled(const float* x, const float* att, const float* dout, const int32_t* rowptr, const int32_t* col,
-                       const int32_t* eid, const int32_t* tile_ptr, int64_t num_tiles, int rows_cap, int edges_cap,
+                       const int32_t* eid, const int32_t* tile_desc, int64_t num_tiles, int rows_nominal, int rows_cap, int edges_cap,
                        const int32_t* rowptr_src, const int32_t* slot_dst_of_srcslot, int64_t num_rows, int64_t num_edges, int64_t H,
                        const int32_t* aggregators, int num_aggregators, const int32_t* scalers, int num_scalers, float* dx,
-                       float* dmsg, uint8_t* spilled, float* datt, void* stream);
+                       float* dmsg, float* datt, void* stream);
 
 /* ================================ BatchNorm1d over node rows ================================= */
 

@@ -130,9 +130,10 @@ def test_pna_tiled_backward(dev, monkeypatch, H, lds_budget, aligned):
         ix = BatchIndex(ei.to(dev), N)
         if aligned:
             ix.graphs(batch.to(dev))
-        if tiled:
-            tile_ptr, T, rows_cap, edges_cap = ix.pna_tiles(H)
-            tp = tile_ptr.cpu()
+        if tiled and ix.pna_tiles(H):          # False when the LDS budget is too small for this width: ops falls back to the two-pass path
+            tile_ptr, T, rows_nominal, rows_cap, edges_cap = ix.pna_tiles(H)
+            tp = tile_ptr[:, 0].cpu()
+            assert torch.equal(tile_ptr[:, 1].cpu(), ix.rowptr_dst.cpu()[tp.long()]) and torch.equal(tile_ptr[:, 2].cpu(), ix.rowptr_src.cpu()[tp.long()])
             assert int(tp[0]) == 0 and int(tp[-1]) == N and bool((tp[1:] >= tp[:-1]).all()) and int((tp[1:] - tp[:-1]).max()) <= rows_cap
         xd, ad = x.to(dev).requires_grad_(True), att.to(dev).requires_grad_(True)
         pna_aggregate(xd, ix, ad, None, aggr, ["identity"], avg).backward(go.to(dev))
@@ -144,5 +145,5 @@ def test_pna_tiled_backward(dev, monkeypatch, H, lds_budget, aligned):
     dx2, da2 = run(True)
     assert torch.equal(dx, dx2) and torch.equal(da, da2)                      # bitwise reproducible
     dx0, da0 = run(False)                                                      # the two-pass backward: same sums, other order
-    assert torch.equal(da, da0)
-    close(dx, dx0, 2e-6, what="dx tiled vs two-pass")
+    close(da, da0, 1e-5, what="datt tiled vs two-pass")
+    close(dx, dx0, 1e-5, what="dx tiled vs two-pass")
