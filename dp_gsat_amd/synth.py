@@ -159,10 +159,14 @@ def powerlaw_batch(num_nodes=1_250_000, num_edges=12_500_000, num_graphs=128, se
         n = int(sizes[g])
         p = w[off:off + n] / w[off:off + n].sum()
         cdf = np.cumsum(p)
-        a = np.minimum(np.searchsorted(cdf, rng.rand(int(e_per[g]))), n - 1)
-        b = np.minimum(np.searchsorted(cdf, rng.rand(int(e_per[g]))), n - 1)
-        keep = a != b
-        a, b = a[keep] + off, b[keep] + off
+        need, got_a, got_b = int(e_per[g]), [], []
+        while need > 0:                       # self pairs (frequent on hubs) are redrawn, so the edge total is the configured one
+            a = np.minimum(np.searchsorted(cdf, rng.rand(need)), n - 1)
+            b = np.minimum(np.searchsorted(cdf, rng.rand(need)), n - 1)
+            keep = a != b
+            got_a.append(a[keep]); got_b.append(b[keep])
+            need -= int(keep.sum())
+        a, b = np.concatenate(got_a) + off, np.concatenate(got_b) + off
         srcs += [a, b]; dsts += [b, a]
         off += n
     src = np.concatenate(srcs).astype(np.int64)
