@@ -62,6 +62,11 @@ def local_shard(name, graphs_per_gpu, rank, world, seed):
     """Weak scaling: the global batch has graphs_per_gpu * world graphs; whole graphs go to ranks by the
     edge-balanced LPT partition (no data-path collective)."""
     from dp_gsat_amd.dist import edges_per_graph, shard_graphs_lpt, take_graphs
+    if name in ("c5", "c5s") and world > 1:
+        # every graph of the power-law workload has the same node and edge count by construction, so the edge-balanced partition
+        # is graphs_per_gpu graphs per rank whichever way it is cut: generate ONLY this rank's graphs (its own seed) instead of
+        # building the 10 M-node / 100 M-edge global batch on every rank
+        return make_batch(name, graphs_per_gpu, seed * 1000 + rank)
     batch, x_dim, e_dim = make_batch(name, graphs_per_gpu * world, seed)
     if world > 1:
         parts = shard_graphs_lpt(edges_per_graph(batch), world)
@@ -187,14 +192,18 @@ def timed(step_fn, steps, warmup, dev, distributed):
 # ------------------------------------------------------------------------------------------------
 # roofline of the masked aggregation kernel: HIP events around back-to-back launches on torch's stream
 # ------------------------------------------------------------------------------------------------
-def aggregation_roofline(wl, data, dev, reps=30, rounds=5):
+def aggregation_roofline(wl, data, dev, reps=30, rounds=5, step_fn=None):
+    """Forward masked-aggregation kernel and the WHOLE aggregation backward (every launch it takes), priced on compulsory bytes.
+    `us_per_launch` = HIP events around back-to-back launches on torch's stream (the launch stream) with the queue kept busy: the
+    kernel's best case.  `in_step_us` = the same launch timed right behind a real hot-path step (cold caches, the state the
+    kernel meets inside the step); rocprofv3's per-kernel average of the bench command (profiles/) agrees with that one."""
     import dp_gsat_amd as G
     from dp_gsat_amd._lib import call, ptr, stream
     N, E, H = data.num_nodes, data.num_edges, wl["H"]
     ix = G.get_index(data.edge_index, N)
+    ix.graphs(data.batch, data.num_graphs)
     x = torch.randn(N, H, device=dev)
     att = torch.rand(E, device=dev)
-    out = {}
     if wl["backbone"] == "PNA":
         A, S = len(PNA_AGGR), 1
         codes = [G.ops.AGGREGATOR_CODES[a] for a in PNA_AGGR]
@@ -213,6 +222,7 @@ def aggregation_roofline(wl, data, dev, reps=30, rounds=5):
                  N, E, H, 1.0, ptr(y), ptr(ix.long_rows[0]), ptr(ix.partial(H)) if ix.long_rows[0] is not None else None, stream())
         alg_bytes = 8 * N * H + 8 * E + 4 * N + (4 * E * H if ee is not None else 0)   # SURVEY 8d (+ edge_emb read for GINE)
         kname = "k_aggr_sum_fwd"
+
     def time_launches(fn):
         for _ in range(5):
             fn()
@@ -229,18 +239,39 @@ def aggregation_roofline(wl, data, dev, reps=30, rounds=5):
             ts.append(start.elapsed_time(end) * 1e-3 / reps)
         return float(np.median(ts))
 
+    def time_in_step(fn, samples=15):
+        """One launch right behind a real step: the queue is never empty (the step is still executing when the launch is
+        enqueued), and the caches hold what the step left, not the kernel's own previous run."""
+        if step_fn is None:
+            return None
+        ts = []
+        for _ in range(samples):
+            start, end = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            step_fn()
+            start.record()
+            fn()
+            end.record()
+            torch.cuda.synchronize(dev)
+            ts.append(start.elapsed_time(end) * 1e-3)
+        return float(np.median(ts))
+
     t = time_launches(launch)
+    t_in = time_in_step(launch)
     achieved = alg_bytes / t / 1e9
     traffic = None          # HBM bytes per launch from rocprofv3 PMC passes (offline, profiles/pmc_traffic.json), same shape only
+    bwd_traffic = None
     try:
         rec = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json"))).get(wl.get("key", ""))
         if rec and rec["algorithmic_bytes_per_launch"] == int(alg_bytes):
             traffic = rec["traffic_bytes_per_launch"]
+            bwd_traffic = rec.get("backward_traffic_bytes")
     except (OSError, ValueError, KeyError):
         pass
     out = dict(bound="hbm", kernel=kname, achieved=round(achieved, 1), peak=HBM_PEAK_GBS, unit="GB/s",
                frac=round(achieved / HBM_PEAK_GBS, 4), traffic=traffic, alg_bytes_per_launch=int(alg_bytes),
                us_per_launch=round(t * 1e6, 2), nodes=N, edges=E)
+    if t_in:
+        out.update(in_step_us=round(t_in * 1e6, 2), frac_in_step=round(alg_bytes / t_in / 1e9 / HBM_PEAK_GBS, 4))
     # what plain streaming passes over a buffer of the kernel's output size reach on this box (SURVEY 8d: quote the vendor
     # peak AND the measured rate): a write-only fill and a device-to-device copy (bytes = read + write)
     y2 = torch.empty_like(y)
@@ -250,15 +281,28 @@ def aggregation_roofline(wl, data, dev, reps=30, rounds=5):
     out["measured_stream"] = dict(fill_GBps=round(fill_gbs, 1), copy_GBps=round(copy_gbs, 1), buffer_bytes=int(y.numel() * 4),
                                   frac_of_fill=round(achieved / fill_gbs, 4), frac_of_copy=round(achieved / copy_gbs, 4))
     del y2
-    # the backward of the same aggregation (by time the largest kernel of the step), priced the same way
+    # the WHOLE backward of the same aggregation -- every launch it takes -- against its compulsory bytes (upstream gradient in,
+    # x in, dx out, att / datt / both index arrays, row pointers); scratch the implementation writes for itself is NOT counted
     if wl["backbone"] == "PNA":
         dout = torch.randn(N, S * A * 2 * H, device=dev)
-        dx_self, dmsg, datt = torch.empty(N, H, device=dev), torch.empty(E, H, device=dev), torch.empty(E, device=dev)
-        def launch_bwd():
-            call("gsat_pna_bwd", ptr(x), ptr(att), None, ptr(dout), ptr(ix.rowptr_dst), ptr(ix.src_by_dst), ptr(ix.eid_by_dst), N, H,
-                 a_arr, A, s_arr, S, 1.0, 1.0, ptr(dx_self), ptr(dmsg), ptr(datt), None, stream())
-        bwd_bytes = 4 * S * A * 2 * N * H + 4 * N * H + 4 * N * H + 4 * E * H + 16 * E + 4 * N   # dout, x, dx_self, dmsg, att/datt/col/eid, rowptr
-        bname = "k_pna_bwd_dst"
+        dx, dmsg, datt = torch.empty(N, H, device=dev), torch.empty(E, H, device=dev), torch.empty(E, device=dev)
+        tiles = ix.pna_tiles(H) if os.environ.get("GSAT_PNA_TILED", "1") != "0" else None
+        if tiles:
+            tile_desc, T, rows_nominal, rows_cap, edges_cap = tiles
+            def launch_bwd():
+                call("gsat_pna_bwd_tiled", ptr(x), ptr(att), ptr(dout), ptr(ix.rowptr_dst), ptr(ix.src_by_dst), ptr(ix.eid_by_dst),
+                     ptr(tile_desc), T, rows_nominal, rows_cap, edges_cap, ptr(ix.rowptr_src), ptr(ix.slot_dst_of_srcslot), N, E, H,
+                     a_arr, A, s_arr, S, ptr(dx), ptr(dmsg), ptr(datt), stream())
+            bname = "k_pna_bwd_tile + k_pna_bwd_spill"
+        else:
+            dx_self = torch.empty(N, H, device=dev)
+            def launch_bwd():
+                call("gsat_pna_bwd", ptr(x), ptr(att), None, ptr(dout), ptr(ix.rowptr_dst), ptr(ix.src_by_dst), ptr(ix.eid_by_dst), N, H,
+                     a_arr, A, s_arr, S, 1.0, 1.0, ptr(dx_self), ptr(dmsg), ptr(datt), None, stream())
+                call("gsat_aggr_sum_fwd", ptr(dmsg), ptr(dx_self), None, None, ptr(ix.rowptr_src), ptr(ix.slot_dst_of_srcslot), None, N, E, H,
+                     1.0, ptr(dx), None, None, stream())
+            bname = "k_pna_bwd_dst + k_aggr_sum_fwd"
+        bwd_bytes = 4 * S * A * 2 * N * H + 4 * N * H + 4 * N * H + 16 * E + 4 * N          # dout, x, dx, att/datt/col/eid, rowptr
     else:
         dout = torch.randn(N, H, device=dev)
         dx, datt = torch.empty(N, H, device=dev), torch.empty(E, device=dev)
@@ -270,8 +314,11 @@ def aggregation_roofline(wl, data, dev, reps=30, rounds=5):
         bwd_bytes = 12 * N * H + 16 * E + 8 * N + (8 * E * H if ee is not None else 0)            # SURVEY 8d (+ edge_emb read, dedge write)
         bname = "k_aggr_sum_bwd"
     tb = time_launches(launch_bwd)
-    out["backward"] = dict(kernel=bname, achieved=round(bwd_bytes / tb / 1e9, 1), frac=round(bwd_bytes / tb / 1e9 / HBM_PEAK_GBS, 4),
-                           alg_bytes_per_launch=int(bwd_bytes), us_per_launch=round(tb * 1e6, 2))
+    tb_in = time_in_step(launch_bwd)
+    out["backward"] = dict(kernels=bname, achieved=round(bwd_bytes / tb / 1e9, 1), frac=round(bwd_bytes / tb / 1e9 / HBM_PEAK_GBS, 4),
+                           compulsory_bytes=int(bwd_bytes), us_all_launches=round(tb * 1e6, 2), traffic=bwd_traffic)
+    if tb_in:
+        out["backward"].update(in_step_us=round(tb_in * 1e6, 2), frac_in_step=round(bwd_bytes / tb_in / 1e9 / HBM_PEAK_GBS, 4))
     return out
 
 
@@ -288,67 +335,92 @@ def _cpu_model():
     return "unknown"
 
 
-def cpu_baseline(wl, name, seed, sample_graphs, steps=5):
+def cpu_baseline(wl, name, seed, sample_graphs=0, warmup=3, steps=10, budget_s=120.0):
+    """SURVEY 8d / BASELINE.md 2: the oracle's scope-A step on the host, FULL batch, 3 warm-up + median of 10 steps, at
+    torch.set_num_threads(5) (the reference's own setting, src/run_gsat.py:1049) and at all physical cores; both are reported,
+    `value` is the faster.  If the protocol at 5 threads would exceed half of `budget_s` the batch is cut to its leading graphs and
+    `sample_fraction` says by how much (edges/s is size-independent to first order: per-graph work); a thread setting that is much
+    slower (oversubscribed cores) stops after the steps that fit its half of the budget (`steps_measured`)."""
     from oracle import bookkeeping as bk
     from oracle import modules as om
     from oracle import ops as oops
     from dp_gsat_amd.dist import take_graphs
     full, _, _ = make_batch(name, wl["graphs"], seed)
-    sample_graphs = min(sample_graphs, full.num_graphs)
-    d = take_graphs(full, range(sample_graphs))
-    N, E, H, L = d.num_nodes, d.num_edges, wl["H"], wl["L"]
-    g = torch.Generator().manual_seed(seed)
-    ext = om.ExtractorMLP(H, wl["edge_att"]).train()
-    emb = torch.randn(N, H, generator=g).requires_grad_(True)
-    xs = [torch.randn(N, H, generator=g).requires_grad_(True) for _ in range(L)]
-    gine = d.edge_attr is not None
-    ees = [torch.randn(E, H, generator=g).requires_grad_(True) for _ in range(L)] if gine else None
-    width = len(PNA_AGGR) * 2 * H if wl["backbone"] == "PNA" else H
-    gouts = [torch.randn(N, width, generator=g) for _ in range(L)]
-    M = E if wl["edge_att"] else N
-    C1 = 4 * H if wl["edge_att"] else 2 * H
 
-    def step():
-        for p in ext.parameters():
-            p.grad = None
-        emb.grad = None
-        u = torch.empty(M, 1).uniform_(1e-10, 1 - 1e-10)
-        masks = [(torch.rand(M, C1) > 0.5).float(), (torch.rand(M, H) > 0.5).float()]
-        z = ext(emb, d.edge_index, d.batch, masks=masks)
-        att = oops.concrete_sample(z, u, True)
-        if wl["edge_att"]:
-            rev = torch.from_numpy(bk.reverse_edge_perm(d.edge_index, N)) if bk.is_undirected(d.edge_index, N) else None
-            edge_att = oops.symmetrise(att, rev)
-        else:
-            edge_att = oops.lift_node_att_to_edge_att(att, d.edge_index)
-        outs = []
-        for l in range(L):
-            if wl["backbone"] == "PNA":
-                outs.append(oops.pna_aggregate(xs[l], d.edge_index, edge_att, PNA_AGGR, ["identity"], {"lin": 1.0, "log": 1.0}))
-            elif gine:
-                outs.append(oops.gine_aggregate(xs[l], d.edge_index, ees[l], edge_att))
+    def build(d):
+        N, E, H, L = d.num_nodes, d.num_edges, wl["H"], wl["L"]
+        g = torch.Generator().manual_seed(seed)
+        ext = om.ExtractorMLP(H, wl["edge_att"]).train()
+        emb = torch.randn(N, H, generator=g).requires_grad_(True)
+        xs = [torch.randn(N, H, generator=g).requires_grad_(True) for _ in range(L)]
+        gine = d.edge_attr is not None
+        ees = [torch.randn(E, H, generator=g).requires_grad_(True) for _ in range(L)] if gine else None
+        width = len(PNA_AGGR) * 2 * H if wl["backbone"] == "PNA" else H
+        gouts = [torch.randn(N, width, generator=g) for _ in range(L)]
+        M = E if wl["edge_att"] else N
+        C1 = 4 * H if wl["edge_att"] else 2 * H
+
+        def step():
+            for p in ext.parameters():
+                p.grad = None
+            emb.grad = None
+            u = torch.empty(M, 1).uniform_(1e-10, 1 - 1e-10)
+            masks = [(torch.rand(M, C1) > 0.5).float(), (torch.rand(M, H) > 0.5).float()]
+            z = ext(emb, d.edge_index, d.batch, masks=masks)
+            att = oops.concrete_sample(z, u, True)
+            if wl["edge_att"]:
+                rev = torch.from_numpy(bk.reverse_edge_perm(d.edge_index, N)) if bk.is_undirected(d.edge_index, N) else None
+                edge_att = oops.symmetrise(att, rev)
             else:
-                outs.append(oops.gin_aggregate(xs[l], d.edge_index, edge_att))
-        torch.autograd.backward(outs, gouts)
+                edge_att = oops.lift_node_att_to_edge_att(att, d.edge_index)
+            outs = []
+            for l in range(L):
+                if wl["backbone"] == "PNA":
+                    outs.append(oops.pna_aggregate(xs[l], d.edge_index, edge_att, PNA_AGGR, ["identity"], {"lin": 1.0, "log": 1.0}))
+                elif gine:
+                    outs.append(oops.gine_aggregate(xs[l], d.edge_index, ees[l], edge_att))
+                else:
+                    outs.append(oops.gin_aggregate(xs[l], d.edge_index, edge_att))
+            torch.autograd.backward(outs, gouts)
+        return step, N, E
 
-    # the reference pins torch.set_num_threads(5) (src/run_gsat.py:1049); also try the host's cores and report the faster
-    results = {}
     default_threads = torch.get_num_threads()
-    for threads in sorted({5, min(default_threads, 32)}):
+    physical = max(1, (os.cpu_count() or 2) // 2)            # SMT host: logical / 2
+    thread_settings = sorted({5, physical})
+    d = full if not sample_graphs else take_graphs(full, range(min(sample_graphs, full.num_graphs)))
+    step, N, E = build(d)
+    torch.set_num_threads(5)
+    t0 = time.perf_counter(); step(); t_probe = time.perf_counter() - t0      # probe at the reference's thread count
+    if not sample_graphs and t_probe * (warmup + steps) > budget_s / 2 and full.num_graphs > 1:
+        keep = max(1, int(full.num_graphs * (budget_s / 2) / (t_probe * (warmup + steps))))
+        d = take_graphs(full, range(keep))
+        step, N, E = build(d)
+    results, measured = {}, {}
+    for threads in thread_settings:
         torch.set_num_threads(threads)
-        step()
+        t_begin = time.perf_counter()
+        for i in range(warmup):
+            step()
+            if time.perf_counter() - t_begin > budget_s / 8:
+                break                                   # a very slow setting (oversubscribed cores): do not burn the budget on warm-up
         ts = []
-        for _ in range(steps):
+        for i in range(steps):
             t0 = time.perf_counter()
             step()
             ts.append(time.perf_counter() - t0)
+            if len(ts) >= 3 and time.perf_counter() - t_begin > budget_s / 2:
+                break
         results[threads] = float(np.median(ts))
+        measured[threads] = len(ts)
     torch.set_num_threads(default_threads)
     threads, t = min(results.items(), key=lambda kv: kv[1])
+    frac = d.num_graphs / full.num_graphs
     return dict(value=round(E / t / 1e6, 5), unit="million edges/s", cores=int(threads), kind="port",
-                sample=f"oracle scope-A step on the first {sample_graphs} of {full.num_graphs} graphs of the workload "
-                       f"({N} nodes, {E} directed edges), 1 warm-up + median of {steps} steps, {t * 1e3:.1f} ms/step",
-                by_threads={str(k): round(E / v / 1e6, 5) for k, v in results.items()}, host_cpus=os.cpu_count(), cpu_model=_cpu_model())
+                sample=f"oracle scope-A step on {d.num_graphs} of {full.num_graphs} graphs of the workload ({N} nodes, {E} directed edges), "
+                       f"{warmup} warm-up + median of {steps} steps per thread setting, {t * 1e3:.1f} ms/step",
+                sample_fraction=round(frac, 4), warmup=warmup, steps=steps, steps_measured={str(k): v for k, v in measured.items()},
+                by_threads={str(k): round(E / v / 1e6, 5) for k, v in results.items()}, physical_cores=physical,
+                host_cpus=os.cpu_count(), cpu_model=_cpu_model())
 
 
 def main():
@@ -444,21 +516,16 @@ def main():
         fdt = timed(fstep, max(args.steps // 2, 3), max(args.warmup // 2, 2), dev, distributed)
         fsteps = max(args.steps // 2, 3)
         full = dict(value=round(e_total / (fdt / fsteps) / 1e6, 3), unit="million edges/s", ms_per_step=round(fdt / fsteps * 1e3, 3),
-                    what="whole GSAT training step: 2 backbone passes + extractor + losses + backward + Adam (+ all-reduce)")
+                    what="whole GSAT training step: 2 backbone passes + extractor + losses + backward + Adam (+ all-reduce)",
+                    gemm_precision="extractor: fp32 MFMA (exact); backbone Linear layers >= 2 GFLOP: bf16x3 (split-bf16, fp32 accumulate)")
 
     G.set_sync_free(False)
     roof, cpu = None, None
     if rank == 0:
         hot.reuse_index = True
-        roof = aggregation_roofline(wl, data, dev)
+        roof = aggregation_roofline(wl, data, dev, step_fn=hot.step)
         if not args.no_cpu_baseline and world == 1:          # reported at N=1 only
-            # bounded sample: leading graphs up to ~60k directed edges (half of the C3 batch: ~10 s of host work over the two
-            # thread settings), never more than half the batch, at least one graph
-            from dp_gsat_amd.dist import edges_per_graph
-            cum = np.cumsum(np.asarray(edges_per_graph(host_batch), dtype=np.int64))
-            fit = int(np.searchsorted(cum, 60_000, side="right"))
-            sample = args.cpu_sample_graphs or max(1, min(fit, wl["graphs"] // 2))
-            cpu = cpu_baseline(wl, args.workload, args.seed, sample)
+            cpu = cpu_baseline(wl, args.workload, args.seed, args.cpu_sample_graphs)
     if distributed:
         dist.barrier()
 
