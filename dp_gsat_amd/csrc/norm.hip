@@ -94,6 +94,16 @@ __global__ __launch_bounds__(NB) void k_bn_finalize(const float* __restrict__ pa
     }
 }
 
+// out[c] = colsum(part): the local (per-rank) sum, handed to the caller for the cross-rank reduction
+__global__ __launch_bounds__(NB) void k_bn_sum_finalize(const float* __restrict__ part, int RB, int C, float* __restrict__ out) {
+    __shared__ float4 sm[NS][NL];
+    const int lane = threadIdx.x % NL, slot = threadIdx.x / NL;
+    const int c = (blockIdx.x * NL + lane) * 4;
+    const bool on = c < C;
+    float4 t = block_colsum(part, RB, C, c, on, sm, slot, lane);
+    if (slot == 0 && on) st4(out + c, t);
+}
+
 __global__ void k_bn_eval_stats(const float* __restrict__ running_mean, const float* __restrict__ running_var, int C, float eps,
                                 float* __restrict__ mean, float* __restrict__ rstd) {
     const int c = blockIdx.x * blockDim.x + threadIdx.x;
@@ -163,9 +173,9 @@ __global__ __launch_bounds__(NB) void k_bn_bwd_finalize(const float* __restrict_
 __global__ void k_bn_bwd_apply(const float* __restrict__ x, const float* __restrict__ dy, const float* __restrict__ mean,
                                const float* __restrict__ rstd, const float* __restrict__ gamma, const float* __restrict__ beta,
                                const float* __restrict__ dbeta, const float* __restrict__ dgamma, int64_t N, int C, int relu, int training,
-                               Tail tail, float* __restrict__ dx, float* __restrict__ dres) {
+                               Tail tail, float* __restrict__ dx, float* __restrict__ dres, float inv_n, const float* __restrict__ rows_dev) {
     const int C4 = C >> 2;
-    const float inv_n = 1.f / (float)N;
+    if (rows_dev) inv_n = 1.f / *rows_dev;            // global row count of a sharded batch, still on the device
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < N * C4; i += (int64_t)gridDim.x * blockDim.x) {
         const int c = (int)(i % C4) * 4;
         float4 v = ld4(x + i * 4), d = ld4(dy + i * 4), mu = ld4(mean + c), rs = ld4(rstd + c), g = ld4(gamma + c), b = ld4(beta + c);
@@ -262,7 +272,8 @@ int gsat_bn_act_bwd(const float* x, const float* dy, const float* gamma, const f
     const Tail tail{nullptr, dropout_p, SeedRef{seed, seed_dev}};
     k_bn_bwd_partial<<<dim3((unsigned)ceil_div(C, 64), (unsigned)RB), NB, 0, stream>>>(x, dy, save_mean, save_rstd, gamma, beta, N, (int)C, relu, rpb, tail, workspace);
     k_bn_bwd_finalize<<<(unsigned)ceil_div(C, 64), NB, 0, stream>>>(workspace, (int)RB, (int)C, dbeta, dgamma);
-    k_bn_bwd_apply<<<ew_grid(N * (C / 4)), 256, 0, stream>>>(x, dy, save_mean, save_rstd, gamma, beta, dbeta, dgamma, N, (int)C, relu, training, tail, dx, dresidual);
+    k_bn_bwd_apply<<<ew_grid(N * (C / 4)), 256, 0, stream>>>(x, dy, save_mean, save_rstd, gamma, beta, dbeta, dgamma, N, (int)C, relu, training, tail, dx, dresidual,
+                                                              1.f / (float)N, nullptr);
     GSAT_LAUNCH_CHECK();
     return GSAT_OK;
 }
@@ -271,6 +282,74 @@ int gsat_bn_bwd(const float* x, const float* dy, const float* gamma, const float
                 int64_t N, int64_t C, int training, int relu, float* dx, float* dgamma, float* dbeta, float* workspace, void* stream_) {
     return gsat_bn_act_bwd(x, dy, gamma, beta, save_mean, save_rstd, N, C, training, relu, 0.f, 0, nullptr, dx, nullptr, dgamma, dbeta,
                            workspace, stream_);
+}
+
+/*
+ * Data-parallel BatchNorm in three local steps with the cross-rank reductions left to the caller (one tiny all-reduce each):
+ *   gsat_bn_local_sum:   out[c] = sum_rows x[r,c]  (centre == NULL)  or  sum_rows (x[r,c] - centre[c])^2
+ *   gsat_bn_apply_fwd:   y = dropout_p( [relu](gamma (x - mean) rstd + beta) + residual ) with GIVEN (global) mean / rstd
+ *   gsat_bn_local_bwd_sums / gsat_bn_apply_bwd: local (sum dy', sum dy' xhat), then dx with the GLOBAL sums and row count
+ */
+int gsat_bn_local_sum(const float* x, const float* centre, int64_t N, int64_t C, float* out, float* workspace, void* stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    GSAT_REQUIRE(N >= 0 && C > 0 && C % 4 == 0 && N < (1ll << 31) && out, GSAT_ERR_ARG, "gsat_bn_local_sum: bad argument");
+    if (N == 0) { GSAT_CHECK_HIP(hipMemsetAsync(out, 0, sizeof(float) * C, stream)); return GSAT_OK; }
+    GSAT_REQUIRE(x && workspace, GSAT_ERR_ARG, "gsat_bn_local_sum: null pointer");
+    int64_t RB, rpb;
+    row_blocks(N, &RB, &rpb);
+    const dim3 grid((unsigned)ceil_div(C, 64), (unsigned)RB);
+    if (centre) k_bn_partial<1><<<grid, NB, 0, stream>>>(x, N, (int)C, rpb, centre, workspace);
+    else k_bn_partial<0><<<grid, NB, 0, stream>>>(x, N, (int)C, rpb, nullptr, workspace);
+    k_bn_sum_finalize<<<(unsigned)ceil_div(C, 64), NB, 0, stream>>>(workspace, (int)RB, (int)C, out);
+    GSAT_LAUNCH_CHECK();
+    return GSAT_OK;
+}
+
+int gsat_bn_apply_fwd(const float* x, const float* gamma, const float* beta, const float* mean, const float* rstd, int64_t N, int64_t C,
+                      int relu, const float* residual, float dropout_p, uint64_t seed, const uint64_t* seed_dev, float* y, void* stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    GSAT_REQUIRE(N >= 0 && C > 0 && C % 4 == 0 && N < (1ll << 31), GSAT_ERR_ARG, "gsat_bn_apply_fwd: bad extents");
+    GSAT_REQUIRE(dropout_p >= 0.f && dropout_p < 1.f, GSAT_ERR_ARG, "gsat_bn_apply_fwd: dropout_p must be in [0, 1)");
+    if (N == 0) return GSAT_OK;
+    GSAT_REQUIRE(x && gamma && beta && mean && rstd && y, GSAT_ERR_ARG, "gsat_bn_apply_fwd: null pointer");
+    const Tail tail{residual, dropout_p, SeedRef{seed, seed_dev}};
+    k_bn_apply<<<ew_grid(N * (C / 4)), 256, 0, stream>>>(x, mean, rstd, gamma, beta, N, (int)C, relu, tail, y);
+    GSAT_LAUNCH_CHECK();
+    return GSAT_OK;
+}
+
+int gsat_bn_local_bwd_sums(const float* x, const float* dy, const float* gamma, const float* beta, const float* mean, const float* rstd,
+                           int64_t N, int64_t C, int relu, float dropout_p, uint64_t seed, const uint64_t* seed_dev, float* sum_dy,
+                           float* sum_dy_xhat, float* workspace, void* stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    GSAT_REQUIRE(N >= 0 && C > 0 && C % 4 == 0 && N < (1ll << 31) && sum_dy && sum_dy_xhat, GSAT_ERR_ARG, "gsat_bn_local_bwd_sums: bad argument");
+    if (N == 0) {
+        GSAT_CHECK_HIP(hipMemsetAsync(sum_dy, 0, sizeof(float) * C, stream));
+        GSAT_CHECK_HIP(hipMemsetAsync(sum_dy_xhat, 0, sizeof(float) * C, stream));
+        return GSAT_OK;
+    }
+    GSAT_REQUIRE(x && dy && gamma && beta && mean && rstd && workspace, GSAT_ERR_ARG, "gsat_bn_local_bwd_sums: null pointer");
+    int64_t RB, rpb;
+    row_blocks(N, &RB, &rpb);
+    const Tail tail{nullptr, dropout_p, SeedRef{seed, seed_dev}};
+    k_bn_bwd_partial<<<dim3((unsigned)ceil_div(C, 64), (unsigned)RB), NB, 0, stream>>>(x, dy, mean, rstd, gamma, beta, N, (int)C, relu, rpb, tail, workspace);
+    k_bn_bwd_finalize<<<(unsigned)ceil_div(C, 64), NB, 0, stream>>>(workspace, (int)RB, (int)C, sum_dy, sum_dy_xhat);
+    GSAT_LAUNCH_CHECK();
+    return GSAT_OK;
+}
+
+int gsat_bn_apply_bwd(const float* x, const float* dy, const float* gamma, const float* beta, const float* mean, const float* rstd,
+                      const float* sum_dy, const float* sum_dy_xhat, int64_t global_rows, const float* global_rows_dev, int64_t N, int64_t C,
+                      int relu, float dropout_p, uint64_t seed, const uint64_t* seed_dev, float* dx, float* dresidual, void* stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    GSAT_REQUIRE(N >= 0 && C > 0 && C % 4 == 0 && N < (1ll << 31) && (global_rows_dev || global_rows >= N), GSAT_ERR_ARG, "gsat_bn_apply_bwd: bad extents");
+    if (N == 0) return GSAT_OK;
+    GSAT_REQUIRE(x && dy && gamma && beta && mean && rstd && sum_dy && sum_dy_xhat && dx, GSAT_ERR_ARG, "gsat_bn_apply_bwd: null pointer");
+    const Tail tail{nullptr, dropout_p, SeedRef{seed, seed_dev}};
+    k_bn_bwd_apply<<<ew_grid(N * (C / 4)), 256, 0, stream>>>(x, dy, mean, rstd, gamma, beta, sum_dy, sum_dy_xhat, N, (int)C, relu, 1, tail, dx, dresidual,
+                                                              global_rows > 0 ? 1.f / (float)global_rows : 0.f, global_rows_dev);
+    GSAT_LAUNCH_CHECK();
+    return GSAT_OK;
 }
 
 }  // extern "C"

@@ -57,7 +57,10 @@ def take_graphs(b: Batch, graph_ids: Iterable[int]) -> Batch:
 
 class FlatGradAllReduce:
     """All parameter gradients live in one flat fp32 buffer (``p.grad`` are views), so a step needs exactly one
-    collective.  ``zero()`` replaces ``optimizer.zero_grad()``; ``all_reduce()`` sums over ranks and scales."""
+    collective.  ``zero_grad()`` replaces ``optimizer.zero_grad()`` (which would unbind the views with set_to_none=True);
+    ``all_reduce()`` sums over ranks and scales.  If something did unbind or replace a ``p.grad`` (an optimizer's or a module's
+    ``zero_grad()``), ``all_reduce()`` notices, copies that gradient into the flat buffer and rebinds the view, so ranks can never
+    step on unreduced gradients."""
 
     def __init__(self, params: Iterable[torch.nn.Parameter], process_group=None):
         self.params = [p for p in params if p.requires_grad]
@@ -65,30 +68,58 @@ class FlatGradAllReduce:
             raise ValueError("no trainable parameters")
         dev, total = self.params[0].device, sum(p.numel() for p in self.params)
         self.flat = torch.zeros(total, dtype=torch.float32, device=dev)
+        self.offsets = []
         off = 0
         for p in self.params:
             if p.dtype != torch.float32 or p.device != dev:
                 raise ValueError("all parameters must be fp32 on one device")
-            p.grad = self.flat[off:off + p.numel()].view_as(p)
+            self.offsets.append(off)
             off += p.numel()
         self.group = process_group
         self._work = None
+        self._scale = 1.0
+        self._bind()
+
+    def _view(self, i):
+        p = self.params[i]
+        return self.flat[self.offsets[i]:self.offsets[i] + p.numel()].view_as(p)
+
+    def _bind(self):
+        """(Re-)attach every ``p.grad`` to its slice of the flat buffer, keeping whatever gradient a stray tensor holds."""
+        base, nbytes = self.flat.data_ptr(), self.flat.numel() * 4
+        for i, p in enumerate(self.params):
+            v = self._view(i)
+            g = p.grad
+            if g is None:
+                v.zero_()                      # no gradient was produced for this parameter in this step
+            elif g.data_ptr() != v.data_ptr() or g.shape != v.shape or not (base <= g.data_ptr() < base + nbytes):
+                v.copy_(g)
+            else:
+                continue
+            p.grad = v
 
     @property
     def nbytes(self) -> int:
         return self.flat.numel() * 4
 
     def zero(self):
+        self._bind()
         self.flat.zero_()
 
+    zero_grad = zero
+
     def all_reduce(self, average: bool = True, async_op: bool = False):
+        """``async_op=True``: the collective is enqueued behind the kernels already on the current stream (the last backward
+        kernel) and runs on the backend's own stream; call ``wait()`` before the optimizer step."""
+        self._bind()
         if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(self.group) == 1:
             return None
         self._work = dist.all_reduce(self.flat, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
         self._scale = 1.0 / dist.get_world_size(self.group) if average else 1.0
-        if not async_op:
-            self.wait()
-        return self._work
+        if async_op:
+            return self._work
+        self.wait()
+        return None
 
     def wait(self):
         if self._work is not None:
@@ -113,7 +144,11 @@ def global_loss_weights(num_local_graphs: int, num_local_rows: int, device, proc
 
 def sync_batchnorm(model: torch.nn.Module, process_group=None) -> torch.nn.Module:
     """BatchNorm statistics over the GLOBAL batch (all ranks), so a sharded run reproduces the single-process model at the
-    same global batch (SURVEY.md 8e).  Uses torch.nn.SyncBatchNorm (one small all-reduce of (sum, sumsq, count) per layer);
-    the local HIP BatchNorm kernels are bypassed for the converted layers.  Off by default: per-rank statistics over
-    ~2k graphs are what plain DDP training uses."""
-    return torch.nn.SyncBatchNorm.convert_sync_batchnorm(model, process_group)
+    same global batch.  The model's own BatchNorm1d modules keep running on the HIP kernels: the local column
+    sums (sum x, sum (x - mean)^2 forward; sum dy, sum dy xhat backward) are all-reduced as [C] vectors between the kernels
+    (dp_gsat_amd.ops.SyncBatchNormFn).  Off by default: per-rank statistics over ~2k graphs are what plain DDP training uses."""
+    from .encoders import BatchNorm1d
+    for m in model.modules():
+        if isinstance(m, BatchNorm1d):
+            m.sync_group = True if process_group is None else process_group
+    return model

@@ -5,7 +5,7 @@ import torch
 import torch.nn as nn
 
 from .graph_index import get_index
-from .ops import BatchNormFn, EmbeddingSum, linear, segment_pool
+from .ops import BatchNormFn, EmbeddingSum, SyncBatchNormFn, linear, segment_pool
 
 # [3P] ogb 1.3.2 get_atom_feature_dims() / get_bond_feature_dims()
 ATOM_FEATURE_DIMS = [119, 5, 12, 12, 10, 6, 6, 2, 2]
@@ -57,7 +57,9 @@ class Linear(nn.Linear):
 class BatchNorm1d(nn.BatchNorm1d):
     """nn.BatchNorm1d (same parameters / buffers / state_dict keys) whose arithmetic runs in libgsat_hip on ROCm tensors
     with 2-D fp32 input; anything else (CPU tensors in the host-protocol tests, odd shapes) uses torch's implementation.
-    ``fused_relu`` applies ReLU inside the kernel (PNA)."""
+    ``fused_relu`` applies ReLU inside the kernel (PNA).  ``sync_group`` (set by dp_gsat_amd.dist.sync_batchnorm) makes the
+    training statistics span every rank of that process group, still on the HIP kernels."""
+    sync_group = None          # None = per-rank statistics; a torch.distributed group (or True = default group) = global statistics
 
     def forward(self, x, fused_relu: bool = False, residual=None, dropout_p: float = 0.0):
         """``residual`` / ``dropout_p``: y = dropout_p(act(BN(x)) + residual) in the same kernels (the PNA layer tail)."""
@@ -81,6 +83,14 @@ class BatchNorm1d(nn.BatchNorm1d):
                 seed_dev = torch.empty(1, dtype=torch.int64, device=x.device).random_()
             else:
                 seed = new_seed()
+        if training and self.sync_group is not None:
+            import torch.distributed as dist
+            if dist.is_available() and dist.is_initialized():
+                group = None if self.sync_group is True else self.sync_group
+                if dist.get_world_size(group) > 1:
+                    return SyncBatchNormFn.apply(x, self.weight, self.bias, self.running_mean if self.track_running_stats else None,
+                                                 self.running_var if self.track_running_stats else None, self.momentum, self.eps, fused_relu,
+                                                 residual, p, seed, seed_dev, group)
         return BatchNormFn.apply(x, self.weight, self.bias, self.running_mean if self.track_running_stats else None,
                                  self.running_var if self.track_running_stats else None, training, self.momentum, self.eps, fused_relu,
                                  residual, p, seed, seed_dev)

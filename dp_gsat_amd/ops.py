@@ -501,6 +501,64 @@ class BatchNormFn(torch.autograd.Function):
         return dx, dgamma, dbeta, None, None, None, None, None, None, dres, None, None, None
 
 
+class SyncBatchNormFn(torch.autograd.Function):
+    """BatchNorm1d (+ the fused PNA layer tail) whose batch statistics span every rank of ``group``: the HIP kernels produce the
+    local column sums, torch.distributed all-reduces the [C] vectors (two small collectives forward, one backward), the HIP kernels
+    apply them.  A sharded run then normalises exactly like the single-process model at the same global batch."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, running_mean, running_var, momentum, eps, relu, residual, dropout_p, seed, seed_dev, group):
+        import torch.distributed as dist
+        from ._lib import load
+        x, weight, bias, residual = _f32c(x), _f32c(weight), _f32c(bias), _f32c(residual)
+        N, C = x.shape
+        dev = x.device
+        ws = torch.empty(max(int(load().gsat_bn_workspace_floats(max(N, 1), C)), 1), dtype=torch.float32, device=dev)
+        stat = torch.empty(C + 1, dtype=torch.float32, device=dev)          # [ sum_c ... | row count ]
+        call("gsat_bn_local_sum", ptr(x), None, N, C, ptr(stat), ptr(ws), stream())
+        stat[C] = float(N)
+        dist.all_reduce(stat, group=group)
+        n_global = stat[C:C + 1].clone()
+        mean = stat[:C] / n_global
+        q = torch.empty(C, dtype=torch.float32, device=dev)
+        call("gsat_bn_local_sum", ptr(x), ptr(mean), N, C, ptr(q), ptr(ws), stream())
+        dist.all_reduce(q, group=group)
+        var = q / n_global
+        rstd = torch.rsqrt(var + eps)
+        if running_mean is not None:
+            with torch.no_grad():
+                running_mean.mul_(1 - momentum).add_(mean, alpha=momentum)
+                running_var.mul_(1 - momentum).add_(q / (n_global - 1).clamp_(min=1), alpha=momentum)     # unbiased, as torch
+        y = torch.empty_like(x)
+        call("gsat_bn_apply_fwd", ptr(x), ptr(weight), ptr(bias), ptr(mean), ptr(rstd), N, C, int(relu), ptr(residual), float(dropout_p),
+             int(seed), ptr(seed_dev), ptr(y), stream())
+        ctx.save_for_backward(x, weight, bias, mean, rstd, n_global)
+        ctx.flags = (bool(relu), float(dropout_p), int(seed), residual is not None)
+        ctx.seed_dev, ctx.group = seed_dev, group
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        import torch.distributed as dist
+        from ._lib import load
+        x, weight, bias, mean, rstd, n_global = ctx.saved_tensors
+        relu, dropout_p, seed, has_res = ctx.flags
+        dy = _f32c(dy)
+        N, C = x.shape
+        dev = x.device
+        ws = torch.empty(max(int(load().gsat_bn_workspace_floats(max(N, 1), C)), 1), dtype=torch.float32, device=dev)
+        sums = torch.empty(2, C, dtype=torch.float32, device=dev)
+        call("gsat_bn_local_bwd_sums", ptr(x), ptr(dy), ptr(weight), ptr(bias), ptr(mean), ptr(rstd), N, C, int(relu), dropout_p, seed,
+             ptr(ctx.seed_dev), ptr(sums[0]), ptr(sums[1]), ptr(ws), stream())
+        dbeta, dgamma = sums[0].clone(), sums[1].clone()       # parameter gradients stay local: they are averaged with the rest
+        dist.all_reduce(sums, group=ctx.group)
+        dx = torch.empty_like(x)
+        dres = torch.empty_like(x) if has_res and ctx.needs_input_grad[8] else None
+        call("gsat_bn_apply_bwd", ptr(x), ptr(dy), ptr(weight), ptr(bias), ptr(mean), ptr(rstd), ptr(sums[0]), ptr(sums[1]),
+             0, ptr(n_global), N, C, int(relu), dropout_p, seed, ptr(ctx.seed_dev), ptr(dx), ptr(dres), stream())
+        return dx, dgamma, dbeta, None, None, None, None, None, dres, None, None, None, None
+
+
 def colsum(x):
     """Deterministic column sum of a 2-D fp32 device tensor (bias gradients)."""
     from ._lib import load

@@ -254,6 +254,27 @@ int gsat_bn_act_bwd(const float* x, const float* dy, const float* gamma, const f
                     float* dbeta, float* workspace, void* stream);
 
 /*
+ * BatchNorm over a batch that is sharded across ranks: the same kernels in separate steps, with the two tiny cross-rank
+ * reductions left to the caller (torch.distributed all-reduce of [C] vectors), so a sharded run reproduces the single-process
+ * statistics at the same global batch:
+ *   forward:  S = all_reduce(gsat_bn_local_sum(x, NULL)); mean = S / N_global;
+ *             Q = all_reduce(gsat_bn_local_sum(x, mean)); rstd = 1/sqrt(Q / N_global + eps); gsat_bn_apply_fwd(...)
+ *   backward: (s1, s2) = all_reduce(gsat_bn_local_bwd_sums(...)); gsat_bn_apply_bwd(..., s1, s2, N_global, ...);
+ *             the parameter gradients dbeta / dgamma are the LOCAL s1 / s2 (they are averaged with all other gradients).
+ * workspace: gsat_bn_workspace_floats(N, C) floats.  replaces: what torch.nn.SyncBatchNorm would do for src/models/gin.py:58, pna.py:45.
+ */
+int gsat_bn_local_sum(const float* x, const float* centre, int64_t N, int64_t C, float* out, float* workspace, void* stream);
+int gsat_bn_apply_fwd(const float* x, const float* gamma, const float* beta, const float* mean, const float* rstd, int64_t N, int64_t C,
+                      int relu, const float* residual, float dropout_p, uint64_t seed, const uint64_t* seed_dev, float* y, void* stream);
+int gsat_bn_local_bwd_sums(const float* x, const float* dy, const float* gamma, const float* beta, const float* mean, const float* rstd,
+                           int64_t N, int64_t C, int relu, float dropout_p, uint64_t seed, const uint64_t* seed_dev, float* sum_dy,
+                           float* sum_dy_xhat, float* workspace, void* stream);
+int gsat_bn_apply_bwd(const float* x, const float* dy, const float* gamma, const float* beta, const float* mean, const float* rstd,
+                      const float* sum_dy, const float* sum_dy_xhat, int64_t global_rows, const float* global_rows_dev /* nullable: device
+                      float overriding global_rows, so the count reduced across ranks never visits the host */, int64_t N, int64_t C,
+                      int relu, float dropout_p, uint64_t seed, const uint64_t* seed_dev, float* dx, float* dresidual, void* stream);
+
+/*
  * out[c] = sum_r x[r,c], two-stage fixed-order reduction (bitwise reproducible).  Bias gradients of the Linear layers
  * (replaces the autograd `sum(0)` of nn.Linear in src/models/gin.py:55-62, src/models/conv_layers.py:153-155).
  * workspace: gsat_colsum_workspace_floats(C) floats.

@@ -301,12 +301,14 @@ def f1_sparsity_loss(p_uv, y_uv, eps=1e-6):
 
 
 class DualGSAT(nn.Module):
-    """src/run_gsat.py:189-281 + 121-149 with explicit randomness; plotting / host copies / eval-mode Gumbel noise dropped
-    (SURVEY App. C, X items)."""
+    """src/run_gsat.py:189-281 + 121-149 with explicit randomness; plotting / host copies dropped.
+    The dual attention is Gumbel-sampled in eval mode too, as the reference does (:222); ``gumbel_noise_in_eval=False`` gives the
+    noise-free sigmoid(logits / tau)."""
 
     def __init__(self, primal_clf, primal_extractor, dual_clf, dual_extractor, primal_cfg, dual_cfg,
-                 primal_learn_edge_att, dual_learn_edge_att):
+                 primal_learn_edge_att, dual_learn_edge_att, gumbel_noise_in_eval=True):
         super().__init__()
+        self.gumbel_noise_in_eval = gumbel_noise_in_eval
         self.primal_clf, self.primal_extractor, self.dual_clf, self.dual_extractor = primal_clf, primal_extractor, dual_clf, dual_extractor
         self.pc, self.dc = primal_cfg, dual_cfg
         self.primal_learn_edge_att, self.dual_learn_edge_att = primal_learn_edge_att, dual_learn_edge_att
@@ -326,7 +328,7 @@ class DualGSAT(nn.Module):
         patt = ops.concrete_sample(plog, primal_u, training)                                                                               # :204
         demb = self.dual_clf.get_emb(dual_data.x, dual_data.edge_index, batch=dual_data.batch, edge_attr=dual_data.edge_attr)             # :208
         dlog = self.dual_extractor(demb, dual_data.edge_index, dual_data.batch, masks=dual_masks)                                          # :209
-        datt = ops.gumbel_sigmoid(dlog, dual_U, tau=0.1) if training else (dlog / 0.1).sigmoid()                                            # :222
+        datt = ops.gumbel_sigmoid(dlog, dual_U, tau=0.1) if (training or self.gumbel_noise_in_eval) else (dlog / 0.1).sigmoid()                                            # :222
         f1 = f1_sparsity_loss(datt, primal_data.edge_label.float())                                                                         # :226
         dual_edge_att = self._edge_att(datt, dual_data, self.dual_learn_edge_att)
         primal_edge_att = self._edge_att(patt, primal_data, self.primal_learn_edge_att)

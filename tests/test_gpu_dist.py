@@ -1,0 +1,108 @@
+"""-m gpu: the HIP path under data parallelism.  Two processes share GPU 0 and talk over gloo (RCCL refuses two ranks on one
+device; the collective backend is not what is under test): LPT whole-graph shards + dist.global_loss_weights + HIP BatchNorm with
+cross-rank statistics (dist.sync_batchnorm) + FlatGradAllReduce must reproduce the single-process HIP gradients, loss and
+BatchNorm running statistics at the same global batch."""
+import os
+import socket
+
+import pytest
+import torch
+import torch.multiprocessing as mp
+
+pytestmark = pytest.mark.gpu
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _build(backbone, edge_att, dev, H=32):
+    import dp_gsat_amd as G
+    from dp_gsat_amd import synth
+    torch.manual_seed(7)
+    data = synth.ba2motifs_batch(num_graphs=12, seed=4)
+    cfg = dict(model_name=backbone, n_layers=2, hidden_size=H, dropout_p=0.0, use_edge_attr=False,
+               aggregators=["mean", "min", "max", "std"], scalers=False, deg=synth.in_degree_histogram(data))
+    clf = G.get_model(10, 0, 2, False, cfg, dev)
+    ext = G.ExtractorMLP(H, edge_att).to(dev)
+    gsat = G.GSAT(clf, ext, G.Criterion(2, False), None, learn_edge_att=edge_att).train()
+    g = torch.Generator().manual_seed(3)
+    M = data.num_edges if edge_att else data.num_nodes
+    C1 = 4 * H if edge_att else 2 * H
+    u = torch.rand(M, 1, generator=g).clamp_(1e-10, 1 - 1e-10)
+    masks = [(torch.rand(M, C1, generator=g) > 0.5).float(), (torch.rand(M, H, generator=g) > 0.5).float()]
+    return data, gsat, u, masks
+
+
+def _worker(rank, world, port, backbone, edge_att, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    import torch.distributed as dist
+    dev = torch.device("cuda:0")
+    torch.cuda.set_device(dev)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        import dp_gsat_amd as G
+        from dp_gsat_amd.dist import (FlatGradAllReduce, edges_per_graph, global_loss_weights, shard_graphs_lpt, sync_batchnorm,
+                                      take_graphs)
+        data, gsat, u, masks = _build(backbone, edge_att, dev)
+        # ---- single-process reference on the whole batch (identical on both ranks) ----
+        _, loss_ref, _, _ = gsat.forward_pass(data.to(dev), 0, True, noise=u.to(dev), dropout_masks=[m.to(dev) for m in masks])
+        loss_ref.backward()
+        ref = {k: p.grad.clone() for k, p in gsat.named_parameters() if p.grad is not None}
+        bn_ref = {k: v.clone() for k, v in gsat.state_dict().items() if "running_" in k}
+        # ---- sharded step: same parameters, fresh BatchNorm buffers ----
+        data2, gsat2, _, _ = _build(backbone, edge_att, dev)
+        gsat2.load_state_dict({k: v for k, v in gsat.state_dict().items() if "running_" not in k and "num_batches" not in k}, strict=False)
+        sync_batchnorm(gsat2)
+        flat = FlatGradAllReduce(gsat2.parameters())
+        parts = shard_graphs_lpt(edges_per_graph(data2), world)
+        mine = take_graphs(data2, parts[rank])
+        gid = torch.tensor(parts[rank])
+        node_sel = torch.isin(data2.batch, gid)
+        edge_sel = node_sel[data2.edge_index[0]]
+        row_sel = edge_sel if edge_att else node_sel
+        wts = global_loss_weights(mine.num_graphs, int(row_sel.sum()), dev)
+        flat.zero_grad()
+        _, loss, _, _ = gsat2.forward_pass(mine.to(dev), 0, True, noise=u[row_sel].to(dev), dropout_masks=[m[row_sel].to(dev) for m in masks],
+                                           loss_weights=wts)
+        for p in gsat2.parameters():          # an optimizer-style zero_grad(set_to_none=True) between forward and backward must not
+            p.grad = None                     # break the flat buffer binding
+        loss.backward()
+        work = flat.all_reduce(average=True, async_op=True)
+        flat.wait()
+        tot = loss.detach().clone()
+        dist.all_reduce(tot)
+        ok, worst = True, 0.0
+        for k, p in gsat2.named_parameters():
+            if k in ref:
+                scale = max(1.0, float(ref[k].abs().max()))
+                err = float((p.grad - ref[k]).abs().max()) / scale
+                worst = max(worst, err)
+                ok = ok and err <= 2e-4 and p.grad.data_ptr() >= flat.flat.data_ptr()
+        bn_err = max([float((gsat2.state_dict()[k] - v).abs().max()) for k, v in bn_ref.items()] + [0.0])
+        loss_err = abs(float(tot) / world - float(loss_ref))
+        q.put((rank, ok and bn_err < 1e-5 and loss_err < 1e-5, worst, bn_err, loss_err, work is not None))
+    except Exception as e:      # surface the failure in the parent instead of a queue timeout
+        import traceback
+        q.put((rank, False, repr(e), traceback.format_exc(), 0, False))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("backbone,edge_att", [("GIN", True), ("PNA", False)])
+def test_sharded_hip_step_matches_single_process(dev, backbone, edge_att):
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, backbone, edge_att, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=600) for _ in procs]
+    for p in procs:
+        p.join(timeout=120)
+    assert all(r[1] for r in res), res
