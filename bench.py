@@ -129,7 +129,8 @@ class HotPath:
                 outs.append(G.ops.masked_sum_aggregate(self.xs[l], index, edge_att, self.edge_emb[l] if self.gine else None))
         torch.autograd.backward(outs, self.gouts)
         if self.flat is not None:
-            self.flat.all_reduce(average=True)
+            self.flat.all_reduce(average=True, async_op=True)
+            self.flat.wait()
 
 
 class FullStep:
@@ -165,7 +166,8 @@ class FullStep:
             self.opt.zero_grad(set_to_none=True)
         loss.backward()
         if self.flat is not None:
-            self.flat.all_reduce(average=True)
+            self.flat.all_reduce(average=True, async_op=True)     # enqueued behind the last backward kernel, on the backend's stream
+            self.flat.wait()                                      # ... and joined right before the optimizer reads the gradients
         self.opt.step()
 
 

@@ -114,12 +114,13 @@ def main():
             w = global_loss_weights(b.num_graphs, b.edge_index.shape[1], dev) if world > 1 else None
             _, loss, ld, _ = gsat.forward_pass(b, epoch, True, loss_weights=w)
             if flat is not None:
-                flat.zero()
+                flat.zero_grad()
             else:
                 opt.zero_grad(set_to_none=True)
             loss.backward()
             if flat is not None:
-                flat.all_reduce(average=True)
+                flat.all_reduce(average=True, async_op=True)
+                flat.wait()
             opt.step()
             tot, nb = tot + ld["loss"], nb + 1
         if rank == 0 and (epoch % 5 == 4 or epoch == args.epochs - 1):
