@@ -360,6 +360,132 @@ __global__ __launch_bounds__(GT) void k_gemm_bf16x3(const float* __restrict__ A,
         }
 }
 
+// ================================================================================================================
+// Weight-stationary kernel for the tall-skinny products of the extractor: C[M,N] = A[M,K] op(B) with M ~ 1e4..1e7 rows and
+// a weight B of at most a few hundred rows and columns.  The 128 x 128 tile kernel above reaches ~50 % of the fp32 MFMA peak at
+// K = 128 / 256: four K-slabs per tile cannot hide the tile prologue / epilogue, and 1.6 rounds of tiles over the chip leave the
+// last round half empty.  Here one persistent 8-wave workgroup per CU keeps ITS SHARE OF B IN REGISTERS for the whole launch
+// (wave w owns the 32 columns of column block w % NB and the k-range of split w / NB: (K/KS)/2 floats per lane) and streams
+// 32-row tiles of A through a double-buffered LDS image; per tile a wave issues (K/KS)/2 back-to-back MFMAs on one accumulator,
+// fed by one conflict-free ds_read_b128 per four MFMAs.  Tiles are dealt round-robin (all cost the same), so the chip is
+// balanced to 1/6 of a CU's share at C3.  With KS > 1 the k-splits of a column block are summed through the idle LDS buffer in
+// fixed order.  The two k-slots of the 32x32x2 MFMA are mapped to the two HALVES of a wave's k-range (a permutation of the
+// summation order only), so every lane reads contiguous k from both operands.
+// ================================================================================================================
+constexpr int WS_THREADS = 512, WS_ROWS = 32;
+
+template <bool B_T, int KR, int NQ>
+__global__ __launch_bounds__(WS_THREADS, (KR <= 64 && NQ <= 4) ? 4 : 2) void k_gemm_ws(
+    const float* __restrict__ A, int64_t lda, const float* __restrict__ B, int64_t ldb, float* __restrict__ C, int64_t ldc, int M, int N,
+    int K, int NB, const float* __restrict__ bias, int tiles) {
+    // KR = (K/KS)/2 floats of B per lane, NQ = K/64 float4 of an A tile per thread.  Small shares (KR <= 64) fit 128 registers:
+    // two workgroups per CU run out of phase, so one's staging / barrier / epilogue hides under the other's MFMAs.
+    extern __shared__ __attribute__((aligned(16))) float ws_lds[];
+    const int LDA = K + 4;                                  // 16-byte slots of consecutive rows fall on distinct bank groups
+    float* const buf0 = ws_lds;
+    float* const buf1 = ws_lds + WS_ROWS * LDA;
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const int cb = wave % NB, ks = wave / NB, KS = 8 / NB;
+    const int Kw = K / KS;                                  // k-range of this wave, = 2 * KR
+    const int c = lane & 31, h = lane >> 5;
+    const int n0 = blockIdx.y * (NB * 32) + cb * 32;        // first output column of this wave
+    const int kbase = ks * Kw + h * KR;                     // this lane's contiguous k-range [kbase, kbase + KR)
+    // ---- this wave's share of B -> registers (once) -----------------------------------------------------
+    float b[KR];
+    if (B_T) {                                              // B[n][k]: KR contiguous floats per lane
+        const float* src = B + (size_t)min(n0 + c, N - 1) * ldb + kbase;
+#pragma unroll
+        for (int q = 0; q < KR / 4; ++q) {
+            const float4 v = ld4(src + 4 * q);
+            b[4 * q] = v.x; b[4 * q + 1] = v.y; b[4 * q + 2] = v.z; b[4 * q + 3] = v.w;
+        }
+    } else {                                                // B[k][n]: a row per k, 32 consecutive columns per half-wave
+#pragma unroll
+        for (int q = 0; q < KR; ++q) b[q] = B[(size_t)(kbase + q) * ldb + min(n0 + c, N - 1)];
+    }
+    const float bv = (bias && ks == 0 && n0 + c < N) ? bias[n0 + c] : 0.f;
+    // ---- A tile staging: 32 x K floats = NQ float4 per thread; thread-constant offsets, one running row pointer ----
+    const int K4 = K >> 2;
+    int srow[NQ], soff[NQ];
+#pragma unroll
+    for (int p = 0; p < NQ; ++p) {
+        const int idx = t + p * WS_THREADS;
+        srow[p] = idx / K4;
+        soff[p] = 4 * (idx % K4);
+    }
+    float4 st[NQ];
+    auto gload = [&](int tile) {
+        const int m0 = tile * WS_ROWS;
+        // rows past M are clamped to the last row instead of zero-filled (their outputs are never stored): a conditional
+        // zero-fill makes the compiler drain every outstanding store of the previous tile before it may overwrite st[]
+#pragma unroll
+        for (int p = 0; p < NQ; ++p) st[p] = ld4(A + (size_t)min(m0 + srow[p], M - 1) * lda + soff[p]);
+    };
+    auto lstore = [&](float* dst) {
+#pragma unroll
+        for (int p = 0; p < NQ; ++p) st4(dst + srow[p] * LDA + soff[p], st[p]);
+    };
+    int tile = blockIdx.x;
+    if (tile < tiles) { gload(tile); lstore(buf0); }
+    // B and the bias are in registers NOW: without this the compiler's wait-count pass, which cannot tell the pre-loop loads from
+    // the loop's own prefetch across the back edge, puts vmcnt(0) in front of the first MFMA of every tile and exposes the
+    // whole latency of the next tile's rows
+    __builtin_amdgcn_s_waitcnt(0x0F70);                     // vmcnt(0)
+    __syncthreads();
+    float* cur = buf0;
+    float* nxt = buf1;
+    const bool col_ok = n0 + c < N;
+    for (; tile < tiles; tile += gridDim.x) {
+        const int ntile = tile + gridDim.x;
+        if (ntile < tiles) gload(ntile);                    // next tile's rows fly under this tile's MFMAs
+        f32x16 acc;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+        const float* arow = cur + c * LDA + kbase;
+#pragma unroll
+        for (int q = 0; q < KR / 4; ++q) {
+            const float4 a4 = ld4(arow + 4 * q);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.x, b[4 * q], acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.y, b[4 * q + 1], acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.z, b[4 * q + 2], acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.w, b[4 * q + 3], acc, 0, 0, 0);
+        }
+        if (KS > 1) {
+            __syncthreads();                                // every wave is done reading `cur`: it becomes the exchange buffer
+            if (ks > 0) {
+                float* part = cur + ((ks - 1) * NB + cb) * 1024;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) part[r * 64 + lane] = acc[r];
+            }
+        }
+        if (ntile < tiles) lstore(nxt);
+        __syncthreads();
+        if (ks == 0) {
+            if (KS > 1) {
+                for (int s2 = 1; s2 < KS; ++s2) {           // fixed order: bitwise reproducible
+                    const float* part = cur + ((s2 - 1) * NB + cb) * 1024;
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) acc[r] += part[r * 64 + lane];
+                }
+            }
+            const int m0 = tile * WS_ROWS;
+            float* crow = C + (size_t)(m0 + 4 * h) * ldc + n0 + c;
+            if (col_ok) {
+                if (m0 + WS_ROWS <= M) {
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) crow[(size_t)((r & 3) + 8 * (r >> 2)) * ldc] = acc[r] + bv;
+                } else {
+#pragma unroll
+                    for (int r = 0; r < 16; ++r)
+                        if (m0 + 4 * h + (r & 3) + 8 * (r >> 2) < M) crow[(size_t)((r & 3) + 8 * (r >> 2)) * ldc] = acc[r] + bv;
+                }
+            }
+        }
+        if (KS > 1) __syncthreads();                        // the exchange buffer is read: the next round may overwrite it
+        float* tmp = cur; cur = nxt; nxt = tmp;
+    }
+}
+
 // out[i] = (accumulate ? out[i] : 0) + sum_s slabs[s][i].  Eight independent partial sums (slab s goes to
 // partial s % 8) keep eight loads in flight; the order is fixed, so the result is bitwise reproducible.
 __global__ void k_slab_reduce(const float* __restrict__ slabs, int nslab, size_t slab_stride, int M, int N, int64_t ldc,
@@ -425,6 +551,59 @@ static bool use_bf16x3(int64_t M, int64_t N, int64_t K, bool allow_split) {
     return allow_split && 2.0 * (double)M * (double)N * (double)K >= 2e9 && K >= 64;
 }
 
+// ---- weight-stationary dispatch ------------------------------------------------------------------------------------
+static bool ws_geometry(int64_t N, int64_t K, int* nb, int* kr) {
+    const int64_t ncols = N > 256 ? 256 : N;              // wider outputs run as 256-column chunks (gridDim.y)
+    if (N % 32 != 0 || (N > 256 && N % 256 != 0) || (K != 64 && K != 128 && K != 256 && K != 512)) return false;
+    const int64_t NB = ncols / 32;
+    if (NB != 1 && NB != 2 && NB != 4 && NB != 8) return false;
+    const int64_t KS = 8 / NB, Kw = K / KS;
+    if (K % KS != 0 || Kw % 8 != 0) return false;
+    const int64_t KR = Kw / 2;
+    if (KR != 16 && KR != 32 && KR != 64 && KR != 128) return false;
+    if ((KS - 1) * NB * 1024 > WS_ROWS * (K + 4)) return false;      // the k-split exchange must fit one A buffer
+    *nb = (int)NB; *kr = (int)KR;
+    return true;
+}
+static bool ws_applicable(int64_t M, int64_t N, int64_t K) {
+    static const int on = getenv("GSAT_GEMM_WS") ? atoi(getenv("GSAT_GEMM_WS")) : 1;
+    int nb, kr;
+    return on && M >= 8192 && M < (1ll << 31) - 64 && ws_geometry(N, K, &nb, &kr);
+}
+template <bool B_T, int KR, int NQ>
+static int ws_launch(hipStream_t stream, dim3 grid, size_t lds, const float* A, int64_t lda, const float* B, int64_t ldb, float* C, int64_t ldc,
+                     int M, int N, int K, int nb, const float* bias, int tiles) {
+    static size_t allowed = 64 * 1024;
+    if (lds > allowed) {
+        GSAT_CHECK_HIP(hipFuncSetAttribute((const void*)k_gemm_ws<B_T, KR, NQ>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        allowed = lds;
+    }
+    k_gemm_ws<B_T, KR, NQ><<<grid, WS_THREADS, lds, stream>>>(A, lda, B, ldb, C, ldc, M, N, K, nb, bias, tiles);
+    GSAT_LAUNCH_CHECK();
+    return GSAT_OK;
+}
+static int gemm_ws(hipStream_t stream, bool b_t, int64_t M, int64_t N, int64_t K, const float* A, int64_t lda, const float* B, int64_t ldb,
+                   float* C, int64_t ldc, const float* bias) {
+    int nb = 0, kr = 0;
+    GSAT_REQUIRE(ws_geometry(N, K, &nb, &kr), GSAT_ERR_UNSUPPORTED, "gemm_ws: unsupported shape");
+    GSAT_REQUIRE(lda % 4 == 0 && ((uintptr_t)A % 16 == 0) && ((uintptr_t)B % 16 == 0) && (!b_t || ldb % 4 == 0), GSAT_ERR_ARG, "gemm_ws: alignment");
+    const int tiles = (int)ceil_div(M, WS_ROWS);
+    const int chunks = (int)ceil_div(N, 256);
+    const size_t lds = (size_t)2 * WS_ROWS * (K + 4) * sizeof(float);
+    const int nq = (int)(K / 64);
+    // persistent workgroups: two per CU where registers and LDS allow it (they run out of phase), tiles dealt round-robin
+    const int per_cu = (kr <= 64 && nq <= 4 && 2 * lds <= 150 * 1024) ? 2 : 1;
+    const dim3 grid((unsigned)std::min<int64_t>(tiles, (int64_t)256 * per_cu / std::min(chunks, per_cu)), (unsigned)chunks);
+#define WSGO(BT, R, Q) return ws_launch<BT, R, Q>(stream, grid, lds, A, lda, B, ldb, C, ldc, (int)M, (int)N, (int)K, nb, bias, tiles)
+#define WSQ(BT, R) do { switch (nq) { case 1: WSGO(BT, R, 1); case 2: WSGO(BT, R, 2); case 4: WSGO(BT, R, 4); case 8: WSGO(BT, R, 8); default: break; } } while (0)
+#define WSKR(BT) do { switch (kr) { case 16: WSQ(BT, 16); break; case 32: WSQ(BT, 32); break; case 64: WSQ(BT, 64); break; default: WSQ(BT, 128); break; } } while (0)
+    if (b_t) WSKR(true); else WSKR(false);
+#undef WSKR
+#undef WSQ
+#undef WSGO
+    GSAT_REQUIRE(false, GSAT_ERR_UNSUPPORTED, "gemm_ws: K = %lld is not 64, 128, 256 or 512", (long long)K);
+}
+
 // C[M,N] (+)= op(A) op(B) (+ bias).  a_t: A given as [K,M]; b_t: B given as [N,K].  K % 4 == 0 and the
 // contiguous extents must be multiples of 4 (float4 staging).  `ws` is needed when gemm_splits() > 1.
 int gemm_f32(hipStream_t stream, bool a_t, bool b_t, int64_t M, int64_t N, int64_t K, const float* A, int64_t lda, const float* B,
@@ -436,8 +615,9 @@ int gemm_f32(hipStream_t stream, bool a_t, bool b_t, int64_t M, int64_t N, int64
                  "gemm_f32: contiguous extents and leading dimensions must be multiples of 4 (M=%lld N=%lld K=%lld)", (long long)M, (long long)N, (long long)K);
     GSAT_REQUIRE(((uintptr_t)A % 16 == 0) && ((uintptr_t)B % 16 == 0) && ((uintptr_t)C % 16 == 0) && ldc % 4 == 0 && (!bias || (uintptr_t)bias % 16 == 0),
                  GSAT_ERR_ARG, "gemm_f32: operands, output and bias must be 16-byte aligned with ldc % 4 == 0");
-    const int splits = gemm_splits(M, N, K, a_t);
     const bool split = use_bf16x3(M, N, K, allow_split);
+    if (!a_t && !split && !accumulate && ws_applicable(M, N, K)) return gemm_ws(stream, b_t, M, N, K, A, lda, B, ldb, C, ldc, bias);
+    const int splits = gemm_splits(M, N, K, a_t);
     int tm = 2, tn = 2;
     if (splits == 1) gemm_tile(M, N, K, &tm, &tn);
     // split-bf16: the per-tile staging (fp32 -> hi/lo, LDS planes) is what costs, so the largest tile wins even when it leaves

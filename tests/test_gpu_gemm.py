@@ -121,3 +121,26 @@ def test_linear_fn_at_backbone_size(dev):
         err = (got.double() - ref).abs().max().item()
         scale = max(1.0, ref.abs().max().item())
         assert err <= 1e-4 * scale, (name, err, scale)
+
+
+@pytest.mark.parametrize("b_t", [True, False])
+@pytest.mark.parametrize("M,N,K", [
+    (51639, 256, 128), (51639, 128, 256),      # C3 node-mode extractor: P = emb W1^T / da1 ; h2 = a1 W2^T / demb  (KS = 1 and 2)
+    (12801, 256, 64), (12801, 64, 256),        # C2 edge mode (H = 64): 8 column blocks x KR 32 ; 2 column blocks x 4 k-splits
+    (9001, 128, 64), (9001, 64, 128),          # H = 64 node mode
+    (20000, 512, 128), (20000, 128, 512),      # C4 edge mode (H = 128): two 256-column chunks ; KR 128
+    (8193, 32, 512),                           # one column block, 8 k-splits
+])
+def test_gemm_weight_stationary(dev, b_t, M, N, K):
+    """The persistent weight-stationary kernel (tall-skinny forward / backward-data products, M >= 8192): every wave geometry,
+    ragged last tile, bias, bitwise determinism."""
+    _run(dev, False, b_t, M, N, K)
+    _run(dev, False, b_t, M, N, K, bias=True)
+    from dp_gsat_amd._lib import call, ptr, stream
+    A = torch.randn(M, K, device=dev); B = torch.randn((N, K) if b_t else (K, N), device=dev)
+    outs = []
+    for _ in range(2):
+        C = torch.empty(M, N, device=dev)
+        call("gsat_gemm_f32", 0, int(b_t), M, N, K, ptr(A), K, ptr(B), B.shape[1], ptr(C), N, None, 0, None, 0, stream())
+        outs.append(C)
+    assert torch.equal(outs[0], outs[1])
