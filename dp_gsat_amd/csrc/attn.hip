@@ -10,6 +10,7 @@
 //     Philox dropout, the head (C2 -> 1 dot + sampler), InstanceNorm backward, deterministic column sums.
 //   * all reductions run in a fixed order (no float atomics): results are bitwise reproducible.
 #include "common.h"
+#include <cstdlib>
 
 namespace gsat {
 
@@ -21,9 +22,14 @@ constexpr int SB_SLOTS = 16;
 // row-major C[M,N] = alpha(=1) * op(A) op(B) + beta(0|1) * C through the hand-written MFMA GEMM (gemm.hip).
 // ta: A is given as [K,M]; tb: B is given as [N,K] (nn.Linear weight layout).
 struct GemmWs { float* ptr; size_t floats; };
+// `split_ok`: the product may run as split-bf16 (relative error ~1e-5 of |A||B|).  Only the BACKWARD products qualify: their
+// results pass through linear maps only (rstd * (dy - mean(dy) - y mean(dy y)), further GEMMs), so the relative error stays
+// 1e-5 of each gradient's own scale.  The forward products feed an InstanceNorm directly: 1/sigma of a nearly constant channel
+// turns the same perturbation of h into ~3e2 x 1e-5 of the normalised value, so they stay exact fp32.
 static int gemm_rm(hipStream_t stream, bool ta, bool tb, int64_t M, int64_t N, int64_t K, const float* A, int64_t lda, const float* B,
-                   int64_t ldb, float beta, float* C, int64_t ldc, GemmWs ws = {nullptr, 0}) {
-    return gemm_f32(stream, ta, tb, M, N, K, A, lda, B, ldb, C, ldc, nullptr, beta != 0.f, ws.ptr, ws.floats);
+                   int64_t ldb, float beta, float* C, int64_t ldc, GemmWs ws = {nullptr, 0}, bool split_ok = false) {
+    static const bool bwd_split = !(getenv("GSAT_ATTN_BWD_SPLIT") && atoi(getenv("GSAT_ATTN_BWD_SPLIT")) == 0);
+    return gemm_f32(stream, ta, tb, M, N, K, A, lda, B, ldb, C, ldc, nullptr, beta != 0.f, ws.ptr, ws.floats, split_ok && bwd_split);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -759,8 +765,8 @@ int gsat_attn_bwd(const gsat_attn_args* a, const gsat_attn_grads* gr, void* stre
         GSAT_LAUNCH_CHECK();
     }
     // dW2[C2,C1] = dh2^T a1 ; da1[M,C1] = dh2 W2
-    if ((rc = gemm_rm(stream, true, false, C2, C1, M, dh2, C2, a->a1, C1, 0.f, gr->dW2, C1, gws))) return rc;
-    if ((rc = gemm_rm(stream, false, false, M, C1, C2, dh2, C2, a->W2, C1, 0.f, da1, C1))) return rc;
+    if ((rc = gemm_rm(stream, true, false, C2, C1, M, dh2, C2, a->a1, C1, 0.f, gr->dW2, C1, gws, true))) return rc;
+    if ((rc = gemm_rm(stream, false, false, M, C1, C2, dh2, C2, a->W2, C1, 0.f, da1, C1, GemmWs{nullptr, 0}, true))) return rc;
     // ---- through ReLU/dropout and the first InstanceNorm ---------------------------------------
     if (Z == 1) {        // statistics and dh1 (in place over da1) in one launch
         if (a->edge_mode) {
@@ -791,18 +797,18 @@ int gsat_attn_bwd(const gsat_attn_args* a, const gsat_attn_grads* gr, void* stre
         if ((rc = aggr_sum_fwd_impl(stream, da1, nullptr, nullptr, nullptr, gr->rowptr_dst, gr->eid_by_dst, nullptr, N, M, C1, 0.f, dQ,
                                     gr->chunk_ptr_dst, lpart))) return rc;
         // demb = dP W1a + dQ W1b ; dW1[:, :H] = dP^T emb ; dW1[:, H:] = dQ^T emb
-        if ((rc = gemm_rm(stream, false, false, N, H, C1, dP, C1, a->W1, 2 * H, 0.f, gr->demb, H))) return rc;
-        if ((rc = gemm_rm(stream, false, false, N, H, C1, dQ, C1, a->W1 + H, 2 * H, 1.f, gr->demb, H))) return rc;
-        if ((rc = gemm_rm(stream, true, false, C1, H, N, dP, C1, a->emb, H, 0.f, gr->dW1, 2 * H, gws))) return rc;
-        if ((rc = gemm_rm(stream, true, false, C1, H, N, dQ, C1, a->emb, H, 0.f, gr->dW1 + H, 2 * H, gws))) return rc;
+        if ((rc = gemm_rm(stream, false, false, N, H, C1, dP, C1, a->W1, 2 * H, 0.f, gr->demb, H, GemmWs{nullptr, 0}, true))) return rc;
+        if ((rc = gemm_rm(stream, false, false, N, H, C1, dQ, C1, a->W1 + H, 2 * H, 1.f, gr->demb, H, GemmWs{nullptr, 0}, true))) return rc;
+        if ((rc = gemm_rm(stream, true, false, C1, H, N, dP, C1, a->emb, H, 0.f, gr->dW1, 2 * H, gws, true))) return rc;
+        if ((rc = gemm_rm(stream, true, false, C1, H, N, dQ, C1, a->emb, H, 0.f, gr->dW1 + H, 2 * H, gws, true))) return rc;
     } else {
         if (Z > 1) {
             PreAct<false> pre{a->P, nullptr, a->b1, nullptr, nullptr, C1};
             k_dh1<false><<<ew_blocks(M * (C1 / 4)), 256, 0, stream>>>(pre, a->row_seg, mean1, rstd1, a->a1, sc, S1p, S2p, M, da1);
             GSAT_LAUNCH_CHECK();
         }
-        if ((rc = gemm_rm(stream, false, false, N, H, C1, da1, C1, a->W1, H, 0.f, gr->demb, H))) return rc;
-        if ((rc = gemm_rm(stream, true, false, C1, H, N, da1, C1, a->emb, H, 0.f, gr->dW1, H, gws))) return rc;
+        if ((rc = gemm_rm(stream, false, false, N, H, C1, da1, C1, a->W1, H, 0.f, gr->demb, H, GemmWs{nullptr, 0}, true))) return rc;
+        if ((rc = gemm_rm(stream, true, false, C1, H, N, da1, C1, a->emb, H, 0.f, gr->dW1, H, gws, true))) return rc;
     }
     return GSAT_OK;
 }
