@@ -290,11 +290,11 @@ def aggregation_roofline(wl, data, dev, reps=30, rounds=5, step_fn=None):
         dx, dmsg, datt = torch.empty(N, H, device=dev), torch.empty(E, H, device=dev), torch.empty(E, device=dev)
         tiles = ix.pna_tiles(H) if os.environ.get("GSAT_PNA_TILED", "1") != "0" else None
         if tiles:
-            tile_desc, T, rows_nominal, rows_cap, edges_cap = tiles
+            tile_desc, T, rows_nominal, rows_cap, edges_cap, spill = tiles
             def launch_bwd():
                 call("gsat_pna_bwd_tiled", ptr(x), ptr(att), ptr(dout), ptr(ix.rowptr_dst), ptr(ix.src_by_dst), ptr(ix.eid_by_dst),
                      ptr(tile_desc), T, rows_nominal, rows_cap, edges_cap, ptr(ix.rowptr_src), ptr(ix.slot_dst_of_srcslot), N, E, H,
-                     a_arr, A, s_arr, S, ptr(dx), ptr(dmsg), ptr(datt), stream())
+                     a_arr, A, s_arr, S, ptr(spill[1:]), ptr(spill[:1]), ptr(dx), ptr(dmsg), ptr(datt), stream())
             bname = "k_pna_bwd_tile + k_pna_bwd_spill"
         else:
             dx_self = torch.empty(N, H, device=dev)

@@ -606,32 +606,51 @@ __global__ __launch_bounds__(TILE_BLOCK, 4) void k_pna_bwd_tile(
     }
 }
 
-// dx[j] += the rows of source j that k_pna_bwd_tile spilled to dmsg, in by-source slot order (rows whose edges all stayed in LDS
-// are not touched).  An edge stayed in LDS iff its by-destination slot lies among the first TE slots of its SOURCE's window.
+// Which sources have an edge that k_pna_bwd_tile will spill is a property of the windows and the two CSRs alone, so it is found
+// ONCE per batch (gsat_pna_build_tiles): spill_rows[0 .. spill_count) lists those sources (order irrelevant: each is independent).
+// An edge stays in LDS iff its by-destination slot lies among the first TE slots of its SOURCE's window.
+__global__ void k_pna_spill_rows(const int4* __restrict__ desc, int TN, int TE, const int32_t* __restrict__ rowptr_src,
+                                 const int32_t* __restrict__ slot_map, int num_rows, int32_t* __restrict__ spill_rows,
+                                 int32_t* __restrict__ spill_count) {
+    const int j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= num_rows) return;
+    const int sb = rowptr_src[j], se = rowptr_src[j + 1];
+    if (sb == se) return;
+    int t = j / TN;                                   // window starts are pulled back by at most TN rows: j is in window t or t + 1
+    if (j >= desc[t + 1].x) ++t;
+    const int k0 = desc[t].y, ne = min(desc[t + 1].y - k0, TE);
+    bool flag = false;
+    for (int s_ = sb; s_ < se && !flag; ++s_) {
+        const int k = slot_map[s_];
+        flag = k < k0 || k >= k0 + ne;
+    }
+    if (flag) spill_rows[atomicAdd(spill_count, 1)] = j;
+}
+
+// dx[j] += the rows of source j that k_pna_bwd_tile spilled to dmsg, in by-source slot order; one lane group per listed source
 template <int LPR>
-__global__ __launch_bounds__(TILE_BLOCK) void k_pna_bwd_spill(const float* __restrict__ dmsg, const int4* __restrict__ desc, int TN, int TE,
-                                                             const int32_t* __restrict__ rowptr_src,
-                                                             const int32_t* __restrict__ slot_map, int num_rows, int H, float* __restrict__ dx) {
-    constexpr int GPB = TILE_BLOCK / LPR;
+__global__ __launch_bounds__(256) void k_pna_bwd_spill(const float* __restrict__ dmsg, const int4* __restrict__ desc, int TN, int TE,
+                                                       const int32_t* __restrict__ rowptr_src, const int32_t* __restrict__ slot_map,
+                                                       const int32_t* __restrict__ spill_rows, const int32_t* __restrict__ spill_count,
+                                                       int H, float* __restrict__ dx) {
+    constexpr int GPB = 256 / LPR;
     const int lane = threadIdx.x % LPR, c = lane * 4;
-    if (c >= H) return;
-    for (int j = blockIdx.x * GPB + threadIdx.x / LPR; j < num_rows; j += gridDim.x * GPB) {
+    const int count = *spill_count;
+    for (int i = blockIdx.x * GPB + threadIdx.x / LPR; i < count; i += gridDim.x * GPB) {
+        const int j = spill_rows[i];
         const int sb = rowptr_src[j], se = rowptr_src[j + 1];
-        if (sb == se) continue;
-        int t = j / TN;                                   // window starts are pulled back by at most TN rows: j is in window t or t + 1
+        int t = j / TN;
         if (j >= desc[t + 1].x) ++t;
-        const int k0 = desc[t].y;
-        const int ne = min(desc[t + 1].y - k0, TE);
-        bool any = false;
-        float4 acc = f4zero();
+        const int k0 = desc[t].y, ne = min(desc[t + 1].y - k0, TE);
+        if (c >= H) continue;
+        float4 acc = ld4(dx + (size_t)j * H + c);
         for (int s_ = sb; s_ < se; ++s_) {
             const int k = slot_map[s_];
             if (k >= k0 && k < k0 + ne) continue;
-            if (!any) { acc = ld4(dx + (size_t)j * H + c); any = true; }
             const float4 v = ld4(dmsg + (size_t)k * H + c);
             acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
         }
-        if (any) st4(dx + (size_t)j * H + c, acc);
+        st4(dx + (size_t)j * H + c, acc);
     }
 }
 
@@ -769,8 +788,9 @@ int gsat_pna_tile_plan(int64_t H, int64_t lds_budget_bytes, int32_t* rows_nomina
     return GSAT_OK;
 }
 
-int gsat_pna_build_tiles(const int32_t* node_ptr, const int32_t* node_seg, const int32_t* rowptr, const int32_t* rowptr_src, int64_t N,
-                         int rows_nominal, int rows_slack, int32_t* tile_desc, void* stream_) {
+int gsat_pna_build_tiles(const int32_t* node_ptr, const int32_t* node_seg, const int32_t* rowptr, const int32_t* rowptr_src,
+                         const int32_t* slot_dst_of_srcslot, int64_t N, int rows_nominal, int rows_slack, int edges_cap, int32_t* tile_desc,
+                         int32_t* spill_rows, int32_t* spill_count, void* stream_) {
     hipStream_t stream = (hipStream_t)stream_;
     GSAT_REQUIRE(N >= 0 && N < (1ll << 31) && rows_nominal > 0 && rows_slack >= 0 && rows_slack <= rows_nominal && tile_desc && rowptr && rowptr_src,
                  GSAT_ERR_ARG, "gsat_pna_build_tiles: bad argument");
@@ -780,14 +800,21 @@ int gsat_pna_build_tiles(const int32_t* node_ptr, const int32_t* node_seg, const
     k_pna_tiles<<<(int)ceil_div(T + 1, 256), 256, 0, stream>>>(node_ptr, node_seg, rowptr, rowptr_src, (int)N, rows_nominal, node_seg ? rows_slack : 0, (int)T,
                                                                (int4*)tile_desc);
     GSAT_LAUNCH_CHECK();
+    GSAT_REQUIRE(spill_rows && spill_count && edges_cap > 0, GSAT_ERR_ARG, "gsat_pna_build_tiles: null spill list");
+    GSAT_CHECK_HIP(hipMemsetAsync(spill_count, 0, sizeof(int32_t), stream));
+    if (N > 0 && slot_dst_of_srcslot) {
+        k_pna_spill_rows<<<(int)ceil_div(N, 256), 256, 0, stream>>>((const int4*)tile_desc, rows_nominal, edges_cap, rowptr_src, slot_dst_of_srcslot,
+                                                                   (int)N, spill_rows, spill_count);
+        GSAT_LAUNCH_CHECK();
+    }
     return GSAT_OK;
 }
 
 int gsat_pna_bwd_tiled(const float* x, const float* att, const float* dout, const int32_t* rowptr, const int32_t* col,
                        const int32_t* eid, const int32_t* tile_desc, int64_t num_tiles, int rows_nominal, int rows_cap, int edges_cap,
                        const int32_t* rowptr_src, const int32_t* slot_dst_of_srcslot, int64_t N, int64_t E, int64_t H,
-                       const int32_t* aggregators, int A, const int32_t* scalers, int S, float* dx, float* dmsg, float* datt,
-                       void* stream_) {
+                       const int32_t* aggregators, int A, const int32_t* scalers, int S, const int32_t* spill_rows,
+                       const int32_t* spill_count, float* dx, float* dmsg, float* datt, void* stream_) {
     hipStream_t stream = (hipStream_t)stream_;
     GSAT_REQUIRE(N >= 0 && N < (1ll << 31) && E >= 0 && num_tiles >= 0, GSAT_ERR_ARG, "gsat_pna_bwd_tiled: bad extents");
     PnaCfg cfg;
@@ -814,9 +841,9 @@ int gsat_pna_bwd_tiled(const float* x, const float* att, const float* dout, cons
 #undef GO
     GSAT_LAUNCH_CHECK();
     if (E > 0) {
-        const int gpb = TILE_BLOCK / lpr;
-        const int nb = (int)std::min<int64_t>(ceil_div(N, gpb), 256 * 16);
-#define CALL(L) k_pna_bwd_spill<L><<<nb, TILE_BLOCK, 0, stream>>>(dmsg, (const int4*)tile_desc, rows_nominal, edges_cap, rowptr_src, slot_dst_of_srcslot, (int)N, (int)H, dx)
+        GSAT_REQUIRE(spill_rows && spill_count, GSAT_ERR_ARG, "gsat_pna_bwd_tiled: null spill list (gsat_pna_build_tiles)");
+        const int nb = (int)std::min<int64_t>(std::max<int64_t>(ceil_div(N, 8 * (256 / lpr)), 1), 256 * 8);     // sized for ~1/8 of the sources
+#define CALL(L) k_pna_bwd_spill<L><<<nb, 256, 0, stream>>>(dmsg, (const int4*)tile_desc, rows_nominal, edges_cap, rowptr_src, slot_dst_of_srcslot, spill_rows, spill_count, (int)H, dx)
         GSAT_LPR_DISPATCH(lpr, CALL);
 #undef CALL
         GSAT_LAUNCH_CHECK();

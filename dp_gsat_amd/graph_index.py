@@ -201,7 +201,7 @@ class BatchIndex:
 
     # -- destination-row windows of the tiled PNA backward -----------------------------------------
     def pna_tiles(self, H: int):
-        """(tile_desc int32[T+1,4], T, rows_nominal, rows_cap, edges_cap) for width H, or None when the tiled backward does not cover H.
+        """(tile_desc int32[T+1,4], T, rows_nominal, rows_cap, edges_cap, spill list) for width H, or None when the tiled backward does not cover H.
         Windows are aligned to graph starts when a batch vector has been registered (graphs()), else fixed."""
         import ctypes
         seg = next(iter(self._graphs.values())) if self._graphs else None
@@ -216,9 +216,11 @@ class BatchIndex:
             return False
         T = (self.N + nominal.value - 1) // nominal.value
         tile_ptr = torch.empty(T + 1, 4, dtype=torch.int32, device=self.device)        # (row, rowptr_dst[row], rowptr_src[row], 0) per window
+        spill = torch.empty(self.N + 1, dtype=torch.int32, device=self.device)       # [0]: count, [1:]: sources with a spilled edge
         call("gsat_pna_build_tiles", ptr(seg.node_ptr) if seg is not None else None, ptr(seg.node_seg32) if seg is not None else None,
-             ptr(self.rowptr_dst), ptr(self.rowptr_src), self.N, nominal.value, slack.value, ptr(tile_ptr), stream())
-        out = (tile_ptr, T, nominal.value, nominal.value + slack.value, ecap.value)
+             ptr(self.rowptr_dst), ptr(self.rowptr_src), ptr(self._slot_dst_of_srcslot) if self.E else None, self.N, nominal.value,
+             slack.value, ecap.value, ptr(tile_ptr), ptr(spill[1:]), ptr(spill[:1]), stream())
+        out = (tile_ptr, T, nominal.value, nominal.value + slack.value, ecap.value, spill)
         self._tiles = {key: out}
         return out
 

@@ -161,11 +161,11 @@ class PnaAggregate(torch.autograd.Function):
             tiles = index.pna_tiles(H) or None
         if tiles is not None:
             # one launch: per-edge gradient rows stay in LDS and are summed per source there (no [E,H] round trip through HBM)
-            tile_ptr, T, rows_nominal, rows_cap, edges_cap = tiles
+            tile_ptr, T, rows_nominal, rows_cap, edges_cap, spill = tiles
             dx = torch.empty_like(x)
             call("gsat_pna_bwd_tiled", ptr(x), ptr(attf), ptr(dout), ptr(index.rowptr_dst), ptr(index.src_by_dst), ptr(index.eid_by_dst),
                  ptr(tile_ptr), T, rows_nominal, rows_cap, edges_cap, ptr(index.rowptr_src), ptr(index.slot_dst_of_srcslot), N, index.E, H,
-                 a_arr, A, s_arr, S, ptr(dx), ptr(dmsg), ptr(datt), stream())
+                 a_arr, A, s_arr, S, ptr(spill[1:]), ptr(spill[:1]), ptr(dx), ptr(dmsg), ptr(datt), stream())
             return dx, (datt.view(ctx.att_shape) if need_att else None), None, None, None, None, None, None
         dx_self = torch.empty_like(x)
         dee = torch.empty_like(edge_emb) if need_ee else None

@@ -208,17 +208,19 @@ int gsat_pna_bwd(const float* x, const float* att, const float* edge_emb, const 
  *                         T = ceil(N / rows_nominal); window t starts at max(start of the graph containing row
  *                         t*rows_nominal, t*rows_nominal - rows_slack) when node_ptr [G+1] / node_seg [N] (gsat_segment_ptr32) are
  *                         given -- block-diagonal batches then lose almost no edge to a window boundary -- else at t*rows_nominal.
+ *                         Also lists, once per batch, the sources that have a spilled edge (spill_rows[0 .. *spill_count), any order).
  *   gsat_pna_bwd_tiled:   rows_cap >= the longest window (rows_nominal + rows_slack <= 2 rows_nominal); dmsg [E,H] is scratch.
  * replaces: autograd backward of PNAConvSimple.message/aggregate (src/models/conv_layers.py:166-185).
  */
 int gsat_pna_tile_plan(int64_t H, int64_t lds_budget_bytes, int32_t* rows_nominal, int32_t* rows_slack, int32_t* edges_cap);
 int gsat_pna_build_tiles(const int32_t* node_ptr, const int32_t* node_seg, const int32_t* rowptr, const int32_t* rowptr_src,
-                         int64_t num_rows, int rows_nominal, int rows_slack, int32_t* tile_desc, void* stream);
+                         const int32_t* slot_dst_of_srcslot, int64_t num_rows, int rows_nominal, int rows_slack, int edges_cap,
+                         int32_t* tile_desc, int32_t* spill_rows /* [num_rows] */, int32_t* spill_count /* [1] */, void* stream);
 int gsat_pna_bwd_tiled(const float* x, const float* att, const float* dout, const int32_t* rowptr, const int32_t* col,
                        const int32_t* eid, const int32_t* tile_desc, int64_t num_tiles, int rows_nominal, int rows_cap, int edges_cap,
                        const int32_t* rowptr_src, const int32_t* slot_dst_of_srcslot, int64_t num_rows, int64_t num_edges, int64_t H,
-                       const int32_t* aggregators, int num_aggregators, const int32_t* scalers, int num_scalers, float* dx,
-                       float* dmsg, float* datt, void* stream);
+                       const int32_t* aggregators, int num_aggregators, const int32_t* scalers, int num_scalers,
+                       const int32_t* spill_rows, const int32_t* spill_count, float* dx, float* dmsg, float* datt, void* stream);
 
 /* ================================ BatchNorm1d over node rows ================================= */
 

@@ -131,7 +131,7 @@ def test_pna_tiled_backward(dev, monkeypatch, H, lds_budget, aligned):
         if aligned:
             ix.graphs(batch.to(dev))
         if tiled and ix.pna_tiles(H):          # False when the LDS budget is too small for this width: ops falls back to the two-pass path
-            tile_ptr, T, rows_nominal, rows_cap, edges_cap = ix.pna_tiles(H)
+            tile_ptr, T, rows_nominal, rows_cap, edges_cap, spill = ix.pna_tiles(H)
             tp = tile_ptr[:, 0].cpu()
             assert torch.equal(tile_ptr[:, 1].cpu(), ix.rowptr_dst.cpu()[tp.long()]) and torch.equal(tile_ptr[:, 2].cpu(), ix.rowptr_src.cpu()[tp.long()])
             assert int(tp[0]) == 0 and int(tp[-1]) == N and bool((tp[1:] >= tp[:-1]).all()) and int((tp[1:] - tp[:-1]).max()) <= rows_cap
