@@ -117,9 +117,7 @@ class HotPath:
             t.grad = None
         index = G.get_index(d.edge_index, self.N)
         index.graphs(d.batch, d.num_graphs)
-        M = self.E if wl["edge_att"] else self.N
-        u = torch.empty(M, 1, device=self.dev).uniform_(1e-10, 1 - 1e-10)
-        _, att = self.ext.attend(self.emb, d.edge_index, d.batch, noise=u)
+        _, att = self.ext.attend(self.emb, d.edge_index, d.batch, noise="philox")      # concrete-sample noise drawn in the head kernel
         edge_att = G.symmetrise_edge_att(att, d.edge_index, self.N) if wl["edge_att"] else G.lift_node_att_to_edge_att(att, d.edge_index)
         outs = []
         for l in range(wl["L"]):
@@ -436,7 +434,11 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-full-step", action="store_true")
     ap.add_argument("--cpu-sample-graphs", type=int, default=0)
-    ap.add_argument("--graph", action="store_true", help="capture the scope-A step into a hipGraph (torch.cuda.graph) and time replays")
+    ap.add_argument("--graph", dest="graph", action="store_true", default=None,
+                    help="capture the step into a hipGraph (torch.cuda.graph) and time replays; DEFAULT on one GPU for c1-c4: the fork's "
+                         "loaders are unshuffled (src/utils/get_data_loaders.py:133,141), so every batch recurs with the same shape each epoch "
+                         "and a per-batch graph is what a training loop would replay; the index is still rebuilt inside every replay")
+    ap.add_argument("--eager", dest="graph", action="store_false", help="plain eager launches (the default for --gpus > 1 and the c5 workloads)")
     ap.add_argument("--sync-free", action="store_true", help="eager launches, but no device->host read inside the step (dp_gsat_amd.set_sync_free)")
     ap.add_argument("--roofline-only", action="store_true", help="only run the aggregation-kernel roofline leg (for rocprofv3 --pmc passes)")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only to rehearse N>1 on one GPU)")
@@ -449,6 +451,8 @@ def main():
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
+    if args.graph is None:
+        args.graph = world == 1 and "RANK" not in os.environ and not big and not args.sync_free
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     # under torchrun (RANK set) the process group is initialised even at world size 1, so the RCCL path can be rehearsed on one GPU
     distributed = world > 1 or ("RANK" in os.environ and "MASTER_PORT" in os.environ)

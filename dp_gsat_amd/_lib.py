@@ -62,6 +62,7 @@ SIGNATURES = {
     "gsat_instance_norm_fwd": (INT, [P, P, P, P, I64, I64, I64, P, P, P]),
     "gsat_instance_norm_bwd": (INT, [P, P, P, P, P, P, I64, I64, I64, P, P, P]),
     "gsat_philox_keep_mask": (INT, [U64, I32, I64, I64, F32, P, P]),
+    "gsat_philox_noise": (INT, [U64, I64, P, P]),
     "gsat_sample_fwd": (INT, [P, P, INT, F32, F32, I64, P, P]),
     "gsat_sample_bwd": (INT, [P, P, F32, I64, P, P]),
     "gsat_lift_fwd": (INT, [P, P, P, I64, P, P]),
@@ -91,7 +92,7 @@ class AttnArgs(ctypes.Structure):
                 ("W1", P), ("b1", P), ("W2", P), ("b2", P), ("W3", P), ("b3", P),
                 ("emb", P), ("mask1", P), ("mask2", P), ("u", P),
                 ("P", P), ("Q", P), ("a1", P), ("h2", P), ("stats", P), ("logits", P), ("att", P),
-                ("fwd_workspace", P), ("fwd_workspace_bytes", SZ), ("seed_dev", P)]
+                ("fwd_workspace", P), ("fwd_workspace_bytes", SZ), ("seed_dev", P), ("noise_philox", I32)]
 
 
 class AttnGrads(ctypes.Structure):

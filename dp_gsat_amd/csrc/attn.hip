@@ -219,7 +219,7 @@ __global__ __launch_bounds__(256) void k_head_fwd(const float* __restrict__ h2, 
                                                   const int32_t* __restrict__ row_seg, const float* __restrict__ mean,
                                                   const float* __restrict__ rstd, const float* __restrict__ mask, SeedRef seed,
                                                   float p, int training, const float* __restrict__ w3, const float* __restrict__ b3,
-                                                  const float* __restrict__ u, int64_t M, int C, float* __restrict__ logits,
+                                                  const float* __restrict__ u, int noise_philox, int64_t M, int C, float* __restrict__ logits,
                                                   float* __restrict__ att) {
     const int lane = threadIdx.x % LPR;
     const float sc = (training && p > 0.f) ? 1.f / (1.f - p) : 1.f;
@@ -243,7 +243,10 @@ __global__ __launch_bounds__(256) void k_head_fwd(const float* __restrict__ h2, 
             logits[m] = z;
             if (att) {
                 float t = z;
-                if (training && u) { float uu = u[m]; t = z + (logf(uu) - logf(1.0f - uu)); }
+                if (training && (u || noise_philox)) {          // concrete sample; the noise is drawn here when the caller passed none
+                    const float uu = u ? u[m] : philox_noise_u(seed.get(), (int)m);
+                    t = z + (logf(uu) - logf(1.0f - uu));
+                }
                 att[m] = 1.f / (1.f + expf(-t));
             }
         }
@@ -506,6 +509,11 @@ __global__ __launch_bounds__(SB) void k_colsum(const float* __restrict__ x, int6
     }
 }
 
+__global__ void k_philox_noise(uint64_t seed, int64_t M, float* __restrict__ u) {
+    const int64_t m = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (m < M) u[m] = philox_noise_u(seed, (int)m);
+}
+
 __global__ void k_philox_mask(uint64_t seed, int layer, int64_t M, int C, float p, float* __restrict__ keep) {
     const int C4 = C >> 2;
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < M * C4; i += (int64_t)gridDim.x * blockDim.x) {
@@ -523,7 +531,7 @@ static inline int ew_blocks(int64_t work_items) {
 static int colsum(hipStream_t stream, const float* x, int64_t R, int C, float* out, float* scratch /* [256*C] */) {
     if (C <= 0) return GSAT_OK;
     const int ctiles = (int)ceil_div(C, 64);
-    if (R <= 0) { GSAT_CHECK_HIP(hipMemsetAsync(out, 0, sizeof(float) * C, stream)); return GSAT_OK; }
+    if (R <= 0) { GSAT_CHECK_HIP(gsat::zero_async(out, sizeof(float) * C, stream)); return GSAT_OK; }
     int64_t RB = std::min<int64_t>(256, ceil_div(R, 64));
     if (RB <= 1) {
         k_colsum<<<dim3(ctiles, 1), SB, 0, stream>>>(x, R, C, R, out);
@@ -655,7 +663,7 @@ int gsat_attn_fwd(const gsat_attn_args* a, void* stream_) {
     const int q = C2 / 4;
     const int lpr = q <= 4 ? 4 : q <= 8 ? 8 : q <= 16 ? 16 : q <= 32 ? 32 : 64;
     const int nb = (int)std::min<int64_t>(ceil_div(M, 256 / lpr), 256 * 32);
-#define HEAD(L) k_head_fwd<L><<<nb, 256, 0, stream>>>(a->h2, a->b2, a->row_seg, mean2, rstd2, a->mask2, SeedRef{a->seed, a->seed_dev}, a->p_drop, a->training, a->W3, a->b3, a->u, M, C2, a->logits, a->att)
+#define HEAD(L) k_head_fwd<L><<<nb, 256, 0, stream>>>(a->h2, a->b2, a->row_seg, mean2, rstd2, a->mask2, SeedRef{a->seed, a->seed_dev}, a->p_drop, a->training, a->W3, a->b3, a->u, a->noise_philox, M, C2, a->logits, a->att)
     switch (lpr) { case 4: HEAD(4); break; case 8: HEAD(8); break; case 16: HEAD(16); break; case 32: HEAD(32); break; default: HEAD(64); break; }
 #undef HEAD
     GSAT_LAUNCH_CHECK();
@@ -694,13 +702,13 @@ int gsat_attn_bwd(const gsat_attn_args* a, const gsat_attn_grads* gr, void* stre
     const int H = a->H, C1 = a->C1, C2 = a->C2;
     const int C0 = a->edge_mode ? 2 * H : H;
     if (M == 0) {
-        GSAT_CHECK_HIP(hipMemsetAsync(gr->demb, 0, sizeof(float) * N * H, stream));
-        GSAT_CHECK_HIP(hipMemsetAsync(gr->dW1, 0, sizeof(float) * C1 * C0, stream));
-        GSAT_CHECK_HIP(hipMemsetAsync(gr->db1, 0, sizeof(float) * C1, stream));
-        GSAT_CHECK_HIP(hipMemsetAsync(gr->dW2, 0, sizeof(float) * C2 * C1, stream));
-        GSAT_CHECK_HIP(hipMemsetAsync(gr->db2, 0, sizeof(float) * C2, stream));
-        GSAT_CHECK_HIP(hipMemsetAsync(gr->dW3, 0, sizeof(float) * C2, stream));
-        GSAT_CHECK_HIP(hipMemsetAsync(gr->db3, 0, sizeof(float), stream));
+        GSAT_CHECK_HIP(gsat::zero_async(gr->demb, sizeof(float) * N * H, stream));
+        GSAT_CHECK_HIP(gsat::zero_async(gr->dW1, sizeof(float) * C1 * C0, stream));
+        GSAT_CHECK_HIP(gsat::zero_async(gr->db1, sizeof(float) * C1, stream));
+        GSAT_CHECK_HIP(gsat::zero_async(gr->dW2, sizeof(float) * C2 * C1, stream));
+        GSAT_CHECK_HIP(gsat::zero_async(gr->db2, sizeof(float) * C2, stream));
+        GSAT_CHECK_HIP(gsat::zero_async(gr->dW3, sizeof(float) * C2, stream));
+        GSAT_CHECK_HIP(gsat::zero_async(gr->db3, sizeof(float), stream));
         return GSAT_OK;
     }
     GSAT_REQUIRE(gr->dlogits || gr->datt, GSAT_ERR_ARG, "gsat_attn_bwd: need dlogits and/or datt");
@@ -838,6 +846,16 @@ int gsat_instance_norm_bwd(const float* y, const float* dy, const float* stats, 
     float* S2 = workspace + (size_t)G * C;
     k_in_bwd_stats<<<dim3((unsigned)G, (unsigned)ceil_div(C, 64), 1), SB, 0, stream>>>(y, dy, seg_ptr, seg_order, (int)C, S1, S2);
     k_in_bwd_apply<<<ew_blocks(M * (C / 4)), 256, 0, stream>>>(y, dy, row_seg, stats + (size_t)G * C, S1, S2, M, (int)C, dx);
+    GSAT_LAUNCH_CHECK();
+    return GSAT_OK;
+}
+
+int gsat_philox_noise(uint64_t seed, int64_t M, float* u, void* stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    GSAT_REQUIRE(M >= 0 && M < (1ll << 31), GSAT_ERR_ARG, "gsat_philox_noise: bad M");
+    if (M == 0) return GSAT_OK;
+    GSAT_REQUIRE(u, GSAT_ERR_ARG, "gsat_philox_noise: null pointer");
+    k_philox_noise<<<(unsigned)ceil_div(M, 256), 256, 0, stream>>>(seed, M, u);
     GSAT_LAUNCH_CHECK();
     return GSAT_OK;
 }

@@ -16,6 +16,17 @@ void set_error(const char* fmt, ...) {
 }
 const char* get_error() { return g_err; }
 
+__global__ void k_zero_words(uint32_t* __restrict__ p, size_t n) {
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) p[i] = 0u;
+}
+hipError_t zero_async(void* p, size_t bytes, hipStream_t stream) {
+    const size_t n = bytes / 4;
+    if (n == 0) return hipSuccess;
+    const unsigned blocks = (unsigned)std::min<size_t>((n + 255) / 256, 256 * 16);
+    k_zero_words<<<blocks, 256, 0, stream>>>(static_cast<uint32_t*>(p), n);
+    return hipGetLastError();
+}
+
 static int bits_for(uint64_t max_value) {   // number of low bits that can be set in [0, max_value]
     int b = 1;
     while (b < 64 && (max_value >> b) != 0) ++b;
@@ -255,7 +266,7 @@ int gsat_build_csr(const int64_t* rows, const int64_t* other, int64_t E, int64_t
     GSAT_REQUIRE(E >= 0 && num_rows >= 0 && rowptr && err_flag, GSAT_ERR_ARG, "gsat_build_csr: bad argument");
     GSAT_REQUIRE(E < (1ll << 31) && num_rows < (1ll << 31), GSAT_ERR_UNSUPPORTED, "gsat_build_csr: >2^31 entries");
     if (E == 0) {
-        GSAT_CHECK_HIP(hipMemsetAsync(rowptr, 0, (size_t)(num_rows + 1) * sizeof(int32_t), stream));
+        GSAT_CHECK_HIP(gsat::zero_async(rowptr, (size_t)(num_rows + 1) * sizeof(int32_t), stream));
         return GSAT_OK;
     }
     GSAT_REQUIRE(rows && perm && num_rows > 0, GSAT_ERR_ARG, "gsat_build_csr: null rows/perm");
@@ -286,7 +297,7 @@ int gsat_reverse_edge_perm(const int64_t* edge_index, int64_t E, int64_t N, int3
     hipStream_t stream = (hipStream_t)stream_;
     GSAT_REQUIRE(E >= 0 && N >= 0 && flags, GSAT_ERR_ARG, "gsat_reverse_edge_perm: bad argument");
     GSAT_REQUIRE(E < (1ll << 30) && N < (1ll << 31), GSAT_ERR_UNSUPPORTED, "gsat_reverse_edge_perm: >2^30 edges");
-    GSAT_CHECK_HIP(hipMemsetAsync(flags, 0, 2 * sizeof(int32_t), stream));
+    GSAT_CHECK_HIP(gsat::zero_async(flags, 2 * sizeof(int32_t), stream));
     if (E == 0) {
         k_finish_flags<<<1, 1, 0, stream>>>(flags);
         GSAT_LAUNCH_CHECK();
@@ -331,10 +342,10 @@ int gsat_build_csr_pair(const int64_t* edge_index, int64_t E, int64_t N, int32_t
                  "gsat_build_csr_pair: bad argument");
     GSAT_REQUIRE(2 * E < (1ll << 31) && 2 * N + 2 < (1ll << 31), GSAT_ERR_UNSUPPORTED, "gsat_build_csr_pair: >2^30 entries");
     if (E == 0) {
-        GSAT_CHECK_HIP(hipMemsetAsync(rowptr_dst, 0, (size_t)(N + 1) * sizeof(int32_t), stream));
-        GSAT_CHECK_HIP(hipMemsetAsync(rowptr_src, 0, (size_t)(N + 1) * sizeof(int32_t), stream));
-        GSAT_CHECK_HIP(hipMemsetAsync(chunk_ptr_dst, 0, (size_t)(N + 1) * sizeof(int32_t), stream));
-        GSAT_CHECK_HIP(hipMemsetAsync(chunk_ptr_src, 0, (size_t)(N + 1) * sizeof(int32_t), stream));
+        GSAT_CHECK_HIP(gsat::zero_async(rowptr_dst, (size_t)(N + 1) * sizeof(int32_t), stream));
+        GSAT_CHECK_HIP(gsat::zero_async(rowptr_src, (size_t)(N + 1) * sizeof(int32_t), stream));
+        GSAT_CHECK_HIP(gsat::zero_async(chunk_ptr_dst, (size_t)(N + 1) * sizeof(int32_t), stream));
+        GSAT_CHECK_HIP(gsat::zero_async(chunk_ptr_src, (size_t)(N + 1) * sizeof(int32_t), stream));
         return GSAT_OK;
     }
     GSAT_REQUIRE(edge_index && src_by_dst && eid_by_dst && dst_by_src && eid_by_src && slot_dst_of_srcslot && N > 0, GSAT_ERR_ARG,
@@ -383,7 +394,7 @@ int gsat_segment_ptr(const int64_t* seg_ids, int64_t n, int64_t num_seg, int32_t
     GSAT_REQUIRE(n >= 0 && num_seg >= 0 && ptr && flags, GSAT_ERR_ARG, "gsat_segment_ptr: bad argument");
     GSAT_REQUIRE(n < (1ll << 31), GSAT_ERR_UNSUPPORTED, "gsat_segment_ptr: >2^31 rows");
     const int B = 256;
-    GSAT_CHECK_HIP(hipMemsetAsync(flags, 0, sizeof(int32_t), stream));
+    GSAT_CHECK_HIP(gsat::zero_async(flags, sizeof(int32_t), stream));
     if (n > 0) {
         GSAT_REQUIRE(seg_ids, GSAT_ERR_ARG, "gsat_segment_ptr: null ids");
         k_check_sorted<<<ceil_div(n, B), B, 0, stream>>>(seg_ids, n, num_seg, flags);

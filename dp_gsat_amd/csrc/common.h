@@ -34,6 +34,11 @@ const char* get_error();
 #define GSAT_LAUNCH_CHECK() GSAT_CHECK_HIP(hipGetLastError())
 
 static inline int64_t ceil_div(int64_t a, int64_t b) { return (a + b - 1) / b; }
+
+// Zero `bytes` (a multiple of 4) of device memory with a KERNEL.  hipMemsetAsync is not used anywhere in the library: inside a
+// captured hipGraph its memset nodes were observed (ROCm 7.2, back-to-back replays of one graph) to run out of order with the
+// kernels of the neighbouring replay -- a counter reset by one raced with the previous replay's readers and writers.
+hipError_t zero_async(void* p, size_t bytes, hipStream_t stream);
 static inline size_t align_up(size_t a, size_t b) { return (a + b - 1) / b * b; }
 
 // Bump allocator over a caller-provided workspace (the library never allocates device memory).
@@ -106,6 +111,14 @@ __device__ __forceinline__ uint4 philox4x32(uint64_t seed, uint32_t c0, uint32_t
         k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
     }
     return make_uint4(c0, c1, c2, c3);
+}
+
+// u in [1e-10, 1 - 1e-10] of the concrete sampler for attention row `row` (Philox stream 4): what `torch.empty_like(z).uniform_(1e-10,
+// 1 - 1e-10)` draws in the reference (example/gsat.py:96), at 23-bit resolution
+__device__ __forceinline__ float philox_noise_u(uint64_t seed, int row) {
+    const uint4 r = philox4x32(seed, (uint32_t)row, 0u, 4u, 0x5A17u);
+    // 23 random bits + a half step: u in [2^-24, 1 - 2^-24], every value exactly representable (1 - 1e-10 rounds to 1.0f in fp32)
+    return ((float)(r.x >> 9) + 0.5f) * (1.0f / 8388608.0f);
 }
 
 // Philox seed by value, or read from device memory (`dev` != NULL): a captured hipGraph then draws a new dropout mask on

@@ -95,7 +95,7 @@ int gsat_onehot_rows(const int64_t* x, const int32_t* dims, int ncol, int64_t N,
     GSAT_REQUIRE(N >= 0 && R_padded >= R && R_padded % 4 == 0, GSAT_ERR_ARG, "gsat_onehot_rows: R_padded must be a multiple of 4 and >= %d", R);
     if (N == 0) return GSAT_OK;
     GSAT_REQUIRE(x && O, GSAT_ERR_ARG, "gsat_onehot_rows: null pointer");
-    GSAT_CHECK_HIP(hipMemsetAsync(O, 0, sizeof(float) * (size_t)N * R_padded, stream));
+    GSAT_CHECK_HIP(gsat::zero_async(O, sizeof(float) * (size_t)N * R_padded, stream));
     k_onehot<<<(unsigned)ceil_div(N * ncol, 256), 256, 0, stream>>>(x, co, N, (int)R_padded, O);
     GSAT_LAUNCH_CHECK();
     return GSAT_OK;

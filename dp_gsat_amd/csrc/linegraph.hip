@@ -158,9 +158,9 @@ int gsat_und_edges(const int64_t* edge_index, int64_t E, int64_t N, uint64_t* so
     hipStream_t stream = (hipStream_t)stream_;
     GSAT_REQUIRE(E >= 0 && N >= 0 && status && rowptr, GSAT_ERR_ARG, "gsat_und_edges: bad argument");
     GSAT_REQUIRE(E < (1ll << 31) && N < (1ll << 31), GSAT_ERR_UNSUPPORTED, "gsat_und_edges: >2^31 entries");
-    GSAT_CHECK_HIP(hipMemsetAsync(status, 0, 4 * sizeof(int32_t), stream));
+    GSAT_CHECK_HIP(gsat::zero_async(status, 4 * sizeof(int32_t), stream));
     if (E == 0) {
-        GSAT_CHECK_HIP(hipMemsetAsync(rowptr, 0, (size_t)(N + 1) * sizeof(int32_t), stream));
+        GSAT_CHECK_HIP(gsat::zero_async(rowptr, (size_t)(N + 1) * sizeof(int32_t), stream));
         return GSAT_OK;
     }
     GSAT_REQUIRE(edge_index && sorted_keys && und_of_slot && und_of_edge && und_src && und_dst && N > 0, GSAT_ERR_ARG,

@@ -262,8 +262,8 @@ int gsat_bn_act_bwd(const float* x, const float* dy, const float* gamma, const f
     GSAT_REQUIRE(dgamma && dbeta, GSAT_ERR_ARG, "gsat_bn_bwd: null gradient output");
     GSAT_REQUIRE(dropout_p >= 0.f && dropout_p < 1.f, GSAT_ERR_ARG, "gsat_bn_act_bwd: dropout_p must be in [0, 1)");
     if (N == 0) {
-        GSAT_CHECK_HIP(hipMemsetAsync(dgamma, 0, sizeof(float) * C, stream));
-        GSAT_CHECK_HIP(hipMemsetAsync(dbeta, 0, sizeof(float) * C, stream));
+        GSAT_CHECK_HIP(gsat::zero_async(dgamma, sizeof(float) * C, stream));
+        GSAT_CHECK_HIP(gsat::zero_async(dbeta, sizeof(float) * C, stream));
         return GSAT_OK;
     }
     GSAT_REQUIRE(x && dy && gamma && beta && save_mean && save_rstd && dx && workspace, GSAT_ERR_ARG, "gsat_bn_bwd: null pointer");
@@ -293,7 +293,7 @@ int gsat_bn_bwd(const float* x, const float* dy, const float* gamma, const float
 int gsat_bn_local_sum(const float* x, const float* centre, int64_t N, int64_t C, float* out, float* workspace, void* stream_) {
     hipStream_t stream = (hipStream_t)stream_;
     GSAT_REQUIRE(N >= 0 && C > 0 && C % 4 == 0 && N < (1ll << 31) && out, GSAT_ERR_ARG, "gsat_bn_local_sum: bad argument");
-    if (N == 0) { GSAT_CHECK_HIP(hipMemsetAsync(out, 0, sizeof(float) * C, stream)); return GSAT_OK; }
+    if (N == 0) { GSAT_CHECK_HIP(gsat::zero_async(out, sizeof(float) * C, stream)); return GSAT_OK; }
     GSAT_REQUIRE(x && workspace, GSAT_ERR_ARG, "gsat_bn_local_sum: null pointer");
     int64_t RB, rpb;
     row_blocks(N, &RB, &rpb);
@@ -324,8 +324,8 @@ int gsat_bn_local_bwd_sums(const float* x, const float* dy, const float* gamma, 
     hipStream_t stream = (hipStream_t)stream_;
     GSAT_REQUIRE(N >= 0 && C > 0 && C % 4 == 0 && N < (1ll << 31) && sum_dy && sum_dy_xhat, GSAT_ERR_ARG, "gsat_bn_local_bwd_sums: bad argument");
     if (N == 0) {
-        GSAT_CHECK_HIP(hipMemsetAsync(sum_dy, 0, sizeof(float) * C, stream));
-        GSAT_CHECK_HIP(hipMemsetAsync(sum_dy_xhat, 0, sizeof(float) * C, stream));
+        GSAT_CHECK_HIP(gsat::zero_async(sum_dy, sizeof(float) * C, stream));
+        GSAT_CHECK_HIP(gsat::zero_async(sum_dy_xhat, sizeof(float) * C, stream));
         return GSAT_OK;
     }
     GSAT_REQUIRE(x && dy && gamma && beta && mean && rstd && workspace, GSAT_ERR_ARG, "gsat_bn_local_bwd_sums: null pointer");

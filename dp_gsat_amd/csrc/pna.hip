@@ -624,7 +624,10 @@ __global__ void k_pna_spill_rows(const int4* __restrict__ desc, int TN, int TE, 
         const int k = slot_map[s_];
         flag = k < k0 || k >= k0 + ne;
     }
-    if (flag) spill_rows[atomicAdd(spill_count, 1)] = j;
+    if (flag) {
+        const int idx = atomicAdd(spill_count, 1);
+        if (idx < num_rows) spill_rows[idx] = j;            // cannot overflow as long as the counter starts at 0; stay in bounds regardless
+    }
 }
 
 // dx[j] += the rows of source j that k_pna_bwd_tile spilled to dmsg, in by-source slot order; one lane group per listed source
@@ -632,10 +635,10 @@ template <int LPR>
 __global__ __launch_bounds__(256) void k_pna_bwd_spill(const float* __restrict__ dmsg, const int4* __restrict__ desc, int TN, int TE,
                                                        const int32_t* __restrict__ rowptr_src, const int32_t* __restrict__ slot_map,
                                                        const int32_t* __restrict__ spill_rows, const int32_t* __restrict__ spill_count,
-                                                       int H, float* __restrict__ dx) {
+                                                       int num_rows, int H, float* __restrict__ dx) {
     constexpr int GPB = 256 / LPR;
     const int lane = threadIdx.x % LPR, c = lane * 4;
-    const int count = *spill_count;
+    const int count = min(*spill_count, num_rows);
     for (int i = blockIdx.x * GPB + threadIdx.x / LPR; i < count; i += gridDim.x * GPB) {
         const int j = spill_rows[i];
         const int sb = rowptr_src[j], se = rowptr_src[j + 1];
@@ -801,7 +804,7 @@ int gsat_pna_build_tiles(const int32_t* node_ptr, const int32_t* node_seg, const
                                                                (int4*)tile_desc);
     GSAT_LAUNCH_CHECK();
     GSAT_REQUIRE(spill_rows && spill_count && edges_cap > 0, GSAT_ERR_ARG, "gsat_pna_build_tiles: null spill list");
-    GSAT_CHECK_HIP(hipMemsetAsync(spill_count, 0, sizeof(int32_t), stream));
+    GSAT_CHECK_HIP(gsat::zero_async(spill_count, sizeof(int32_t), stream));
     if (N > 0 && slot_dst_of_srcslot) {
         k_pna_spill_rows<<<(int)ceil_div(N, 256), 256, 0, stream>>>((const int4*)tile_desc, rows_nominal, edges_cap, rowptr_src, slot_dst_of_srcslot,
                                                                    (int)N, spill_rows, spill_count);
@@ -843,7 +846,7 @@ int gsat_pna_bwd_tiled(const float* x, const float* att, const float* dout, cons
     if (E > 0) {
         GSAT_REQUIRE(spill_rows && spill_count, GSAT_ERR_ARG, "gsat_pna_bwd_tiled: null spill list (gsat_pna_build_tiles)");
         const int nb = (int)std::min<int64_t>(std::max<int64_t>(ceil_div(N, 8 * (256 / lpr)), 1), 256 * 8);     // sized for ~1/8 of the sources
-#define CALL(L) k_pna_bwd_spill<L><<<nb, 256, 0, stream>>>(dmsg, (const int4*)tile_desc, rows_nominal, edges_cap, rowptr_src, slot_dst_of_srcslot, spill_rows, spill_count, (int)H, dx)
+#define CALL(L) k_pna_bwd_spill<L><<<nb, 256, 0, stream>>>(dmsg, (const int4*)tile_desc, rows_nominal, edges_cap, rowptr_src, slot_dst_of_srcslot, spill_rows, spill_count, (int)N, (int)H, dx)
         GSAT_LPR_DISPATCH(lpr, CALL);
 #undef CALL
         GSAT_LAUNCH_CHECK();

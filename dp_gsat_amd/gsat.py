@@ -54,22 +54,28 @@ class ExtractorMLP(nn.Module):
 
     def attend(self, emb, edge_index, batch, noise=None, dropout_masks=None, seed=None):
         """(att_log_logits, att): logits and the sampled attention from ONE fused pipeline.
-        ``noise``: uniform u in (0,1) per row -> concrete sample in training mode; None -> sigmoid(logits).
+        ``noise``: uniform u in (0,1) per row -> concrete sample in training mode; None -> sigmoid(logits); the string
+        "philox" -> concrete sample with u drawn inside the head kernel (Philox stream 4 of the step's seed, no noise tensor).
         ``dropout_masks``: optional explicit keep-masks [(M,C1),(M,C2)] (parity tests); default Philox(seed)."""
         index = get_index(edge_index, emb.shape[0])
         segments = index.graphs(batch)
         l1, l2, l3 = self.mlp.linears()
         m1, m2 = dropout_masks if dropout_masks is not None else (None, None)
+        philox_noise = isinstance(noise, str)
+        if philox_noise:
+            if noise != "philox":
+                raise ValueError("noise must be a tensor, None or 'philox'")
+            noise = None
         seed_dev = None
         if seed is None:
-            need = self.training and self.mlp.dropout_p > 0 and m1 is None
+            need = self.training and ((self.mlp.dropout_p > 0 and m1 is None) or philox_noise)
             if need and sync_free():
                 # graph-capturable: the seed lives on the device and is redrawn by a graph-safe RNG op on every replay
                 seed, seed_dev = 0, torch.empty(1, dtype=torch.int64, device=emb.device).random_()
             else:
                 seed = new_seed() if need else 0
         return ExtractorAttention.apply(emb, l1.weight, l1.bias, l2.weight, l2.bias, l3.weight, l3.bias, index, segments,
-                                        self.edge_mode, self.training, self.mlp.dropout_p, seed, m1, m2, noise, seed_dev)
+                                        self.edge_mode, self.training, self.mlp.dropout_p, seed, m1, m2, noise, seed_dev, philox_noise)
 
     def forward(self, emb, edge_index, batch, type: Optional[str] = None, dropout_masks=None):
         if type is not None and self.type is not None and type != self.type:
@@ -163,8 +169,7 @@ class GSAT(nn.Module):
             get_index(data.edge_index, N).graphs(data.batch, int(num_graphs))
         emb = self.clf.get_emb(data.x, data.edge_index, batch=data.batch, edge_attr=data.edge_attr)
         if training and noise is None:
-            M = data.edge_index.shape[1] if self.learn_edge_att else N
-            noise = torch.empty(M, 1, device=emb.device).uniform_(1e-10, 1 - 1e-10)
+            noise = "philox"            # u ~ U(1e-10, 1 - 1e-10) (example/gsat.py:96) drawn inside the head kernel: no uniform_ launch, no tensor
         _, att = self.extractor.attend(emb, data.edge_index, data.batch, noise if training else None, dropout_masks)
         if self.learn_edge_att:
             edge_att = symmetrise_edge_att(att, data.edge_index, N)

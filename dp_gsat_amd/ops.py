@@ -189,7 +189,7 @@ def pna_aggregate(x, index, att, edge_emb, aggregators, scalers, avg_deg):
 # ------------------------------------------------------------------------------------------------
 # attention extractor MLP (+ fused concrete sampler)
 # ------------------------------------------------------------------------------------------------
-def _attn_args(emb, params, index, segments, edge_mode, training, p, seed, mask1, mask2, u, bufs, seed_dev=None):
+def _attn_args(emb, params, index, segments, edge_mode, training, p, seed, mask1, mask2, u, bufs, seed_dev=None, noise_philox=False):
     from ._lib import AttnArgs
     W1, b1, W2, b2, W3, b3 = params
     N, H = emb.shape
@@ -209,6 +209,7 @@ def _attn_args(emb, params, index, segments, edge_mode, training, p, seed, mask1
     P, Q, a1, h2, stats, logits, att = bufs
     a.P, a.Q, a.a1, a.h2, a.stats, a.logits, a.att = ptr(P), ptr(Q), ptr(a1), ptr(h2), ptr(stats), ptr(logits), ptr(att)
     a.seed_dev = ptr(seed_dev)
+    a.noise_philox = int(bool(noise_philox) and u is None)
     return a
 
 
@@ -219,7 +220,7 @@ class ExtractorAttention(torch.autograd.Function):
     (example/gsat.py:94-103,131-139; src/utils/get_model.py:47-68; src/run_gsat.py:877-927)."""
 
     @staticmethod
-    def forward(ctx, emb, W1, b1, W2, b2, W3, b3, index, segments, edge_mode, training, p, seed, mask1, mask2, u, seed_dev=None):
+    def forward(ctx, emb, W1, b1, W2, b2, W3, b3, index, segments, edge_mode, training, p, seed, mask1, mask2, u, seed_dev=None, noise_philox=False):
         import ctypes
         emb = _f32c(emb)
         params = tuple(_f32c(t) for t in (W1, b1, W2, b2, W3, b3))
@@ -248,7 +249,7 @@ class ExtractorAttention(torch.autograd.Function):
         logits = torch.empty(M, 1, dtype=f32, device=dev)
         att = torch.empty(M, 1, dtype=f32, device=dev)
         bufs = (P, Q, a1, h2, stats, logits, att)
-        args = _attn_args(emb, params, index, segments, edge_mode, training, p, seed, mask1, mask2, u, bufs, seed_dev)
+        args = _attn_args(emb, params, index, segments, edge_mode, training, p, seed, mask1, mask2, u, bufs, seed_dev, noise_philox)
         from ._lib import load
         fws_bytes = int(load().gsat_attn_fwd_workspace_bytes(ctypes.byref(args)))
         if fws_bytes:
@@ -291,7 +292,7 @@ class ExtractorAttention(torch.autograd.Function):
         ws = torch.empty(ws_bytes, dtype=torch.uint8, device=emb.device)
         g.workspace, g.workspace_bytes = ptr(ws), ws_bytes
         call("gsat_attn_bwd", ctypes.byref(args), ctypes.byref(g), stream())
-        return (demb, *grads, None, None, None, None, None, None, None, None, None, None)
+        return (demb, *grads, None, None, None, None, None, None, None, None, None, None, None)
 
 
 def new_seed() -> int:

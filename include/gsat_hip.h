@@ -369,6 +369,8 @@ typedef struct gsat_attn_args {
     void* fwd_workspace;       /* gsat_attn_fwd_workspace_bytes() bytes (0 for batches of small graphs) */
     size_t fwd_workspace_bytes;
     const uint64_t* seed_dev;  /* nullable DEVICE word overriding `seed` (hipGraph replays: new dropout mask per replay) */
+    int32_t noise_philox;      /* != 0 with `training` and u == NULL: draw the concrete sampler's u in the kernel (Philox stream 4 of
+                                  `seed`, row-keyed) instead of reading a tensor -- the reference's uniform_ launch (example/gsat.py:96) */
 } gsat_attn_args;
 
 typedef struct gsat_attn_grads {
@@ -398,6 +400,9 @@ int gsat_instance_norm_fwd(const float* x, const int32_t* seg_ptr, const int32_t
 int gsat_instance_norm_bwd(const float* y, const float* dy, const float* stats, const int32_t* seg_ptr,
                            const int32_t* seg_order, const int32_t* row_seg, int64_t M, int64_t G,
                            int64_t C, float* dx, float* workspace /* [G*2*C] */, void* stream);
+
+/* u[m]: the concrete sampler's noise gsat_attn_fwd draws for row m when noise_philox is set (parity tests pass it back explicitly) */
+int gsat_philox_noise(uint64_t seed, int64_t M, float* u, void* stream);
 
 /* keep[m,c] in {0,1}: the Philox dropout mask gsat_attn_* uses for (seed, layer, row m, column c). */
 int gsat_philox_keep_mask(uint64_t seed, int32_t layer, int64_t M, int64_t C, float p_drop, float* keep,

@@ -172,3 +172,36 @@ def test_reorder_like(dev):
     bad = ei.clone(); bad[1, 0] = (bad[1, 0] + 1) % N
     with pytest.raises(ValueError):
         G.reorder_like(bad.to(dev), ei.to(dev), vals.to(dev))
+
+
+def test_in_kernel_concrete_noise(dev):
+    """noise="philox": the concrete sampler's u is drawn inside the head kernel (no uniform_ launch).  The draw is
+    exactly gsat_philox_noise(seed), so passing that tensor explicitly must give bitwise the same attention and gradients; the
+    noise is uniform on (0, 1) and changes with the seed."""
+    import dp_gsat_amd as G
+    from dp_gsat_amd._lib import call, ptr, stream
+    ei, batch, N = random_batch(3, 40, 5, 30)
+    E = ei.shape[1]
+    for edge_mode, M in ((True, E), (False, N)):
+        ext = G.ExtractorMLP(32, edge_mode).to(dev).train()
+        emb = torch.randn(N, 32, device=dev)
+        ga = torch.randn(M, 1, device=dev)
+        seed = 12345
+        u = torch.empty(M, 1, device=dev)
+        call("gsat_philox_noise", seed, M, ptr(u), stream())
+        outs = []
+        for noise in ("philox", u):
+            e = emb.clone().requires_grad_(True)
+            z, a = ext.attend(e, ei.to(dev), batch.to(dev), noise=noise, seed=seed)
+            a.backward(ga)
+            outs.append((z.detach(), a.detach(), e.grad))
+        for x, y in zip(*outs):
+            assert torch.equal(x, y)
+        a2 = ext.attend(emb, ei.to(dev), batch.to(dev), noise="philox", seed=seed + 1)[1]
+        assert not torch.equal(a2, outs[0][1])
+        uu = torch.empty(200_000, device=dev)
+        call("gsat_philox_noise", 7, uu.numel(), ptr(uu), stream())
+        assert 0.0 < float(uu.min()) and float(uu.max()) < 1.0
+        assert abs(float(uu.mean()) - 0.5) < 5e-3 and abs(float(uu.var()) - 1.0 / 12.0) < 2e-3
+        hist = torch.histc(uu, bins=20, min=0.0, max=1.0) / uu.numel()
+        assert float((hist - 0.05).abs().max()) < 3e-3

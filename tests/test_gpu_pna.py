@@ -147,3 +147,55 @@ def test_pna_tiled_backward(dev, monkeypatch, H, lds_budget, aligned):
     dx0, da0 = run(False)                                                      # the two-pass backward: same sums, other order
     close(da, da0, 1e-5, what="datt tiled vs two-pass")
     close(dx, dx0, 1e-5, what="dx tiled vs two-pass")
+
+
+def test_pna_tiled_backward_under_back_to_back_graph_replays(dev):
+    """The whole per-batch pipeline (index build -> window build with its spill-source list -> PNA forward -> tiled backward)
+    captured into one hipGraph and replayed back to back WITHOUT host syncs must reproduce the eager result bit for bit on every
+    replay.  (Round 2 found hipMemsetAsync nodes racing with the neighbouring replay's kernels: the spill counter was reset out
+    of order, overflowed its list and faulted; the library now zeroes with kernels only.)"""
+    import dp_gsat_amd as G
+    from dp_gsat_amd import synth
+    from dp_gsat_amd.ops import pna_aggregate
+    data = synth.molhiv_batch(512, seed=3).to(dev)
+    N, E, H = data.num_nodes, data.num_edges, 128
+    aggr, avg = ["mean", "min", "max", "std"], {"lin": 1.0, "log": 1.0}
+    g = torch.Generator(device=dev).manual_seed(1)
+    x = torch.randn(N, H, device=dev, generator=g).requires_grad_(True)
+    att = torch.rand(E, 1, device=dev, generator=g).requires_grad_(True)
+    go = torch.randn(N, 8 * H, device=dev, generator=g)
+    dx_buf, da_buf = torch.zeros(N, H, device=dev), torch.zeros(E, 1, device=dev)
+
+    def fn():
+        G.clear_cache()
+        ix = G.get_index(data.edge_index, N)
+        ix.graphs(data.batch, data.num_graphs)
+        x.grad = None
+        att.grad = None
+        pna_aggregate(x, ix, att, None, aggr, ["identity"], avg).backward(go)
+        dx_buf.copy_(x.grad)
+        da_buf.copy_(att.grad)
+
+    fn()
+    torch.cuda.synchronize()
+    want_dx, want_da = dx_buf.clone(), da_buf.clone()
+    G.set_sync_free(True)
+    try:
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            for _ in range(3):
+                fn()
+        torch.cuda.current_stream().wait_stream(side)
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph):
+            fn()
+        for r in range(3):
+            dx_buf.zero_(); da_buf.zero_()
+            for _ in range(25):
+                graph.replay()
+            torch.cuda.synchronize()
+            assert torch.equal(dx_buf, want_dx) and torch.equal(da_buf, want_da), f"round {r}"
+    finally:
+        G.set_sync_free(False)
+        G.clear_cache()

@@ -2,12 +2,12 @@
 # Runs the bench on every single-GPU workload, eager and captured (hipGraph), and prints one condensed line per run.
 cd "$(dirname "$0")/.."
 for wl in c3 c1 c2 c4; do
-  for mode in "" "--graph"; do
-    python bench.py --workload $wl $mode --no-cpu-baseline 2>/dev/null | tail -1 | python -c "
+  for mode in "--eager" "--graph"; do
+    python bench.py --workload $wl $mode --no-cpu-baseline 2>gpurun_out/matrix_$wl$mode.err | tail -1 | python -c "
 import sys, json
 r = json.loads(sys.stdin.read())
 f = r.get('full_step') or {}
-print('$wl', '${mode:-eager}', 'scopeA_ms', r['ms_per_step'], 'Medges/s', r['value'], 'full_ms', f.get('ms_per_step'), 'roof', r['roofline']['kernel'], r['roofline']['us_per_launch'], r['roofline']['frac'], 'bwd', r['roofline']['backward']['us_per_launch'], r['roofline']['backward']['frac'])
+print('$wl', '${mode}', 'scopeA_ms', r['ms_per_step'], 'Medges/s', r['value'], 'full_ms', f.get('ms_per_step'), 'roof', r['roofline']['kernel'], r['roofline']['us_per_launch'], r['roofline']['frac'], 'bwd', r['roofline']['backward']['us_all_launches'], r['roofline']['backward']['frac'], 'in_step', r['roofline'].get('in_step_us'), r['roofline']['backward'].get('in_step_us'))
 "
   done
 done
