@@ -5,9 +5,10 @@
 //   * edge mode evaluates layer 1 on NODES: P = emb W1a^T, Q = emb W1b^T, h1_e = P[src_e]+Q[dst_e]+b1.
 //     The [E,2H] concat, the E-row first GEMM and h1 itself are never materialised; the InstanceNorm
 //     statistics kernel and the a1 producer recompute h1 from two gathered rows.
-//   * dense contractions (P/Q, h2 = a1 W2^T and their gradients) go through rocBLAS sgemm (true fp32
-//     MFMA, atomics off); everything else is hand-written: segmented statistics, normalise + ReLU +
-//     Philox dropout, the head (C2 -> 1 dot + sampler), InstanceNorm backward, deterministic column sums.
+//   * dense contractions (P/Q, h2 = a1 W2^T and their gradients) go through the hand-written MFMA GEMMs of gemm.hip:
+//     forward products exact fp32 (weight-stationary k_gemm_ws / tile kernel k_gemm_f32), backward products split-bf16;
+//     the rest: segmented statistics, normalise + ReLU + Philox dropout, the head (C2 -> 1 dot + sampler, noise drawn
+//     in the kernel when no tensor is given), InstanceNorm backward, deterministic column sums.
 //   * all reductions run in a fixed order (no float atomics): results are bitwise reproducible.
 #include "common.h"
 #include <cstdlib>

@@ -36,7 +36,7 @@ extern "C" {
 #define GSAT_ERR_ARG (-2)        /* bad argument (null pointer, negative extent, unsupported width) */
 #define GSAT_ERR_WORKSPACE (-3)  /* workspace too small */
 #define GSAT_ERR_UNSUPPORTED (-4)
-#define GSAT_ERR_BLAS (-5)
+#define GSAT_ERR_BLAS (-5)         /* reserved: no entry point returns it since the library GEMMs were replaced (round 1) */
 
 int gsat_abi_version(void);
 const char* gsat_last_error(void);
