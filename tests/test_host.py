@@ -34,7 +34,8 @@ def test_library_exports_every_declared_symbol():
 
 def test_ctypes_structs_match_header_layout():
     from dp_gsat_amd._lib import AttnArgs, AttnGrads
-    assert ctypes.sizeof(AttnArgs) == 3 * 8 + 5 * 4 + 4 + 8 + 24 * 8 + 8   # 3 i64, 5 i32, float, u64, 24 pointers, size_t
+    # 3 i64, 5 i32, float, u64, 24 pointers, size_t, then noise_philox (i32) + 4 bytes of tail padding
+    assert ctypes.sizeof(AttnArgs) == 3 * 8 + 5 * 4 + 4 + 8 + 24 * 8 + 8 + 8
     assert ctypes.sizeof(AttnGrads) == 16 * 8 + 8
 
 
