@@ -205,3 +205,48 @@ def test_in_kernel_concrete_noise(dev):
         assert abs(float(uu.mean()) - 0.5) < 5e-3 and abs(float(uu.var()) - 1.0 / 12.0) < 2e-3
         hist = torch.histc(uu, bins=20, min=0.0, max=1.0) / uu.numel()
         assert float((hist - 0.05).abs().max()) < 3e-3
+
+
+@pytest.mark.parametrize("edge_mode", [True, False])
+@pytest.mark.parametrize("H", [32, 128, 320])
+def test_extractor_mixed_segment_lengths(dev, H, edge_mode):
+    """Batches mixing one-row, short and long (150-210 row) graphs in the unsliced statistics path, also at widths that are not a
+    power of two and need several 64-channel column blocks (H = 320: C1 = 640 / 1280)."""
+    import dp_gsat_amd as G
+    from tests.graphs import random_batch as rb
+    parts = [rb(7, 30, 2, 14), rb(8, 1, 150, 150), rb(9, 20, 3, 9), rb(10, 1, 210, 210), rb(11, 1, 1, 1)]
+    eis, batches, off, goff = [], [], 0, 0
+    for ei_p, b_p, n_p in parts:
+        eis.append(ei_p + off)
+        batches.append(b_p + goff)
+        off += n_p
+        goff += int(b_p.max()) + 1
+    ei, batch, N = torch.cat(eis, dim=1), torch.cat(batches), off
+    ei = shuffle_edges(ei, 4)
+    E = ei.shape[1]
+    M = E if edge_mode else N
+    g = torch.Generator().manual_seed(H)
+    emb = torch.randn(N, H, generator=g)
+    C1, C2 = (4 * H, H) if edge_mode else (2 * H, H)
+    masks = [(torch.rand(M, C1, generator=g) > 0.5).float(), (torch.rand(M, C2, generator=g) > 0.5).float()]
+    u = torch.rand(M, 1, generator=g).clamp_(1e-10, 1 - 1e-10)
+    ga = torch.randn(M, 1, generator=g)
+    oext = om.ExtractorMLP(H, edge_mode)
+    ref = {}
+    for dt in (torch.float32, torch.float64):
+        ext = om.ExtractorMLP(H, edge_mode).to(dt).train()
+        ext.load_state_dict({k: v.to(dt) for k, v in oext.state_dict().items()})
+        e = emb.to(dt).clone().requires_grad_(True)
+        a = oops.concrete_sample(ext(e, ei, batch, masks=[m.to(dt) for m in masks]), u.to(dt), True)
+        a.backward(ga.to(dt))
+        ref[dt] = dict(a=a, demb=e.grad, **{k: p.grad for k, p in ext.named_parameters()})
+    ext = G.ExtractorMLP(H, edge_mode).to(dev).train()
+    ext.load_state_dict(oext.state_dict())
+    ed = emb.to(dev).requires_grad_(True)
+    _, a = ext.attend(ed, ei.to(dev), batch.to(dev), noise=u.to(dev), dropout_masks=[m.to(dev) for m in masks])
+    a.backward(ga.to(dev))
+    r32, r64 = ref[torch.float32], ref[torch.float64]
+    close(a, r32["a"], ref64=r64["a"], what="att")
+    close(ed.grad, r32["demb"], 2e-4, ref64=r64["demb"], what="demb")
+    for k, p in ext.named_parameters():
+        close(p.grad, r32[k], 2e-4, ref64=r64[k], what=k)
