@@ -72,10 +72,33 @@ constexpr int WAVE = 64;
 
 // sum over the `width` consecutive lanes of an aligned lane group (width = power of two <= 64)
 template <int WIDTH> __device__ __forceinline__ float group_sum(float v) {
+    if constexpr ((WIDTH & (WIDTH - 1)) == 0) {
 #pragma unroll
-    for (int o = WIDTH / 2; o > 0; o >>= 1) v += __shfl_xor(v, o, WIDTH);
+        for (int o = WIDTH / 2; o > 0; o >>= 1) v += __shfl_xor(v, o, WIDTH);
+    } else {
+        // lane groups that are not a power of two wide (20 lanes = 80 channels, three groups per wave): a shift-down tree over the
+        // group's lanes; only lane 0 of the group holds the full sum (which is all the callers read)
+        const int l = (int)(threadIdx.x & 63) % WIDTH;
+#pragma unroll
+        for (int o = 16; o > 0; o >>= 1) {
+            const float t = __shfl_down(v, o, 64);
+            if (l + o < WIDTH) v += t;
+        }
+    }
     return v;
 }
+
+// Lane-group geometry shared by the row kernels: LPR lanes (one float4 each) own a row; a wave carries 64 / LPR groups and the
+// lanes beyond the last whole group idle (LPR = 20: three rows per wave, lanes 60-63 idle).  Groups never straddle a wave.
+template <int LPR, int BLOCK> struct LaneGroups {
+    static constexpr int GPW = 64 / LPR, GPB = (BLOCK / 64) * GPW;
+    int grp, lane;       // group within the block (or -1 for an idle lane), lane within the group
+    __device__ __forceinline__ LaneGroups() {
+        const int wl = threadIdx.x & 63, sub = wl / LPR;
+        lane = wl % LPR;
+        grp = sub < GPW ? (int)(threadIdx.x >> 6) * GPW + sub : -1;
+    }
+};
 
 __device__ __forceinline__ float4 ld4(const float* p) { return *reinterpret_cast<const float4*>(p); }
 __device__ __forceinline__ void st4(float* p, float4 v) { *reinterpret_cast<float4*>(p) = v; }

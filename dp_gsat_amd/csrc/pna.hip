@@ -93,14 +93,16 @@ __global__ __launch_bounds__(PNA_BLOCK) void k_pna_fwd(
     const float* __restrict__ x, const float* __restrict__ att, const float* __restrict__ edge_emb,
     const int32_t* __restrict__ rowptr, const int32_t* __restrict__ col, const int32_t* __restrict__ eid,
     int num_rows, int H, PnaCfg cfg, float* __restrict__ out, int rows_per_group) {
-    constexpr int GPB = PNA_BLOCK / LPR;
-    const int lane = threadIdx.x % LPR;
+    const LaneGroups<LPR, PNA_BLOCK> lg;
+    constexpr int GPB = LaneGroups<LPR, PNA_BLOCK>::GPB;
+    const int lane = lg.lane;
     const int c = lane * 4;
     const bool on = c < H;
     const int parts = HAS_EE ? 3 : 2;
     const int F = parts * H;
     const size_t out_stride = (size_t)cfg.S * cfg.A * F;
-    const int grp = pna_xcd_remap(blockIdx.x, gridDim.x) * GPB + threadIdx.x / LPR;
+    if (lg.grp < 0) return;
+    const int grp = pna_xcd_remap(blockIdx.x, gridDim.x) * GPB + lg.grp;
     int row = grp * rows_per_group;
     const int row_end = min(num_rows, row + rows_per_group);
     for (; row < row_end; ++row) {
@@ -171,12 +173,13 @@ __global__ __launch_bounds__(PNA_BLOCK, HAS_EE ? 2 : 4) void k_pna_bwd_dst(
     const float* __restrict__ dout, const int32_t* __restrict__ rowptr, const int32_t* __restrict__ col,
     const int32_t* __restrict__ eid, int num_rows, int H, PnaCfg cfg, float* __restrict__ dx_self,
     float* __restrict__ dmsg, float* __restrict__ datt, float* __restrict__ dedge, int rows_per_group) {
-    constexpr int GPB = PNA_BLOCK / LPR;
+    const LaneGroups<LPR, PNA_BLOCK> lg;
+    constexpr int GPB = LaneGroups<LPR, PNA_BLOCK>::GPB;
     // The upstream gradient row (S*A*parts segments of H floats, 64 % of the kernel's bytes) is fetched by LDS-DMA at
     // the top of the row, so its HBM latency overlaps the index -> att -> x_j dependency chain without holding VGPRs.
     constexpr int MAXSEG = NAGG ? NAGG * (HAS_EE ? 3 : 2) : 8;
     __shared__ float4 stage[MAXSEG][PNA_BLOCK];
-    const int lane = threadIdx.x % LPR;
+    const int lane = lg.lane;
     const int c = lane * 4;
     const bool on = c < H;
     const int parts = HAS_EE ? 3 : 2;
@@ -185,7 +188,8 @@ __global__ __launch_bounds__(PNA_BLOCK, HAS_EE ? 2 : 4) void k_pna_bwd_dst(
     const int nseg = cfg.S * cfg.A * parts;
     const bool staged = NAGG != 0 || nseg <= MAXSEG;
     const int wave_base = (threadIdx.x >> 6) << 6;
-    const int grp = pna_xcd_remap(blockIdx.x, gridDim.x) * GPB + threadIdx.x / LPR;
+    if (lg.grp < 0) return;
+    const int grp = pna_xcd_remap(blockIdx.x, gridDim.x) * GPB + lg.grp;
     int row = grp * rows_per_group;
     const int row_end = min(num_rows, row + rows_per_group);
     for (; row < row_end; ++row) {
@@ -422,7 +426,7 @@ __global__ __launch_bounds__(TILE_BLOCK, 4) void k_pna_bwd_tile(
     const int32_t* __restrict__ col, const int32_t* __restrict__ eid, const int4* __restrict__ desc,
     const int32_t* __restrict__ rowptr_src, const int32_t* __restrict__ slot_map, int H, int TE, int RCAP, float* dx,
     float* __restrict__ dmsg, float* __restrict__ datt) {
-    constexpr int GPB = TILE_BLOCK / LPR;        // lane groups (rows in flight) per workgroup
+    constexpr int GPB = LaneGroups<LPR, TILE_BLOCK>::GPB;     // lane groups (rows in flight) per workgroup
     constexpr int RPW = 64 / LPR;                // rows covered by one wave-instruction
     constexpr int NSEG = NAGG * 2;
     extern __shared__ float4 smem4[];
@@ -434,8 +438,10 @@ __global__ __launch_bounds__(TILE_BLOCK, 4) void k_pna_bwd_tile(
     int* s_rp = s_slot + TE;                                     // [RCAP+1] by-destination row pointers relative to the window's first slot
     int* s_rps = s_rp + RCAP + 1;                                // [RCAP+1] by-source row pointers relative to the window's first slot
     const int tid = threadIdx.x, wave = tid >> 6;
-    const int grp = tid / LPR, lane = tid % LPR, c = lane * 4;
-    const bool on = c < H;
+    const LaneGroups<LPR, TILE_BLOCK> lg;
+    const int grp = lg.grp < 0 ? GPB : lg.grp;          // idle lanes (LPR = 20: lanes 60-63) behave like a group beyond every row
+    const int lane = lg.lane, c = lane * 4;
+    const bool on = c < H && lg.grp >= 0;
     const int t = pna_xcd_remap(blockIdx.x, gridDim.x);
     const int4 d0 = desc[t], d1 = desc[t + 1];
     const int n0 = d0.x, n1 = d1.x;
@@ -447,7 +453,7 @@ __global__ __launch_bounds__(TILE_BLOCK, 4) void k_pna_bwd_tile(
     float4 dcur[NSEG];
     float4 xi_cur = f4zero();
     const size_t out_stride = (size_t)NSEG * H;
-    int row = n0 + grp;
+    int row = lg.grp >= 0 ? n0 + grp : n1;               // idle lanes own no row
 #pragma unroll
     for (int sg = 0; sg < NSEG; ++sg) dcur[sg] = f4zero();
     if (row < n1 && on) {
@@ -591,7 +597,7 @@ __global__ __launch_bounds__(TILE_BLOCK, 4) void k_pna_bwd_tile(
     }
     __syncthreads();
     // ---- per-source sums over the rows kept in LDS (same lane group <-> row map as above: dx[j] is this thread's own store) ----
-    for (int j = n0 + grp; j < n1; j += GPB) {
+    for (int j = lg.grp >= 0 ? n0 + grp : n1; j < n1; j += GPB) {
         if (!on) continue;
         const int sb = s_rps[j - n0], se = s_rps[j - n0 + 1];
         float4 acc = ld4(dx + (size_t)j * H + c);
@@ -636,10 +642,12 @@ __global__ __launch_bounds__(256) void k_pna_bwd_spill(const float* __restrict__
                                                        const int32_t* __restrict__ rowptr_src, const int32_t* __restrict__ slot_map,
                                                        const int32_t* __restrict__ spill_rows, const int32_t* __restrict__ spill_count,
                                                        int num_rows, int H, float* __restrict__ dx) {
-    constexpr int GPB = 256 / LPR;
-    const int lane = threadIdx.x % LPR, c = lane * 4;
+    const LaneGroups<LPR, 256> lg;
+    constexpr int GPB = LaneGroups<LPR, 256>::GPB;
+    const int lane = lg.lane, c = lane * 4;
     const int count = min(*spill_count, num_rows);
-    for (int i = blockIdx.x * GPB + threadIdx.x / LPR; i < count; i += gridDim.x * GPB) {
+    if (lg.grp < 0) return;
+    for (int i = blockIdx.x * GPB + lg.grp; i < count; i += gridDim.x * GPB) {
         const int j = spill_rows[i];
         const int sb = rowptr_src[j], se = rowptr_src[j + 1];
         int t = j / TN;
@@ -660,11 +668,12 @@ __global__ __launch_bounds__(256) void k_pna_bwd_spill(const float* __restrict__
 static inline int pna_lpr(int64_t H) {
     if (H <= 0 || H % 4 != 0 || H > 256) return 0;
     int64_t q = H / 4;
-    return q <= 4 ? 4 : q <= 8 ? 8 : q <= 16 ? 16 : q <= 32 ? 32 : 64;
+    // 80 channels (the hidden size of every PNA YAML of the reference): 20-lane groups, three rows per wave instead of two
+    return q <= 4 ? 4 : q <= 8 ? 8 : q <= 16 ? 16 : q <= 20 ? 20 : q <= 32 ? 32 : 64;
 }
 
 static inline void pna_grid(int64_t N, int lpr, int* nb, int* rpg) {
-    const int gpb = PNA_BLOCK / lpr;
+    const int gpb = (PNA_BLOCK / 64) * (64 / lpr);
     int64_t b = ceil_div(N, gpb);
     if (b > 256 * 64) b = 256 * 64;          // one row per lane group up to 16k blocks: shorter per-wave dependency chains
     if (b < 1) b = 1;
@@ -713,7 +722,7 @@ static size_t pna_tile_lds_bytes(int lpr, int edges_cap, int rows_cap) {
 using namespace gsat;
 
 #define GSAT_LPR_DISPATCH(lpr, CALL) \
-    switch (lpr) { case 4: CALL(4); break; case 8: CALL(8); break; case 16: CALL(16); break; case 32: CALL(32); break; default: CALL(64); break; }
+    switch (lpr) { case 4: CALL(4); break; case 8: CALL(8); break; case 16: CALL(16); break; case 20: CALL(20); break; case 32: CALL(32); break; default: CALL(64); break; }
 
 extern "C" {
 
@@ -845,7 +854,7 @@ int gsat_pna_bwd_tiled(const float* x, const float* att, const float* dout, cons
     GSAT_LAUNCH_CHECK();
     if (E > 0) {
         GSAT_REQUIRE(spill_rows && spill_count, GSAT_ERR_ARG, "gsat_pna_bwd_tiled: null spill list (gsat_pna_build_tiles)");
-        const int nb = (int)std::min<int64_t>(std::max<int64_t>(ceil_div(N, 8 * (256 / lpr)), 1), 256 * 8);     // sized for ~1/8 of the sources
+        const int nb = (int)std::min<int64_t>(std::max<int64_t>(ceil_div(N, 8 * 4 * (64 / lpr)), 1), 256 * 8);     // sized for ~1/8 of the sources
 #define CALL(L) k_pna_bwd_spill<L><<<nb, 256, 0, stream>>>(dmsg, (const int4*)tile_desc, rows_nominal, edges_cap, rowptr_src, slot_dst_of_srcslot, spill_rows, spill_count, (int)N, (int)H, dx)
         GSAT_LPR_DISPATCH(lpr, CALL);
 #undef CALL

@@ -209,6 +209,9 @@ class BatchIndex:
         hit = self._tiles.get(key)
         if hit is not None:
             return hit
+        if H < 64:            # narrow rows: the two-pass backward is as fast or faster (profiles/r02_summary.md, width table)
+            self._tiles[key] = False
+            return False
         nominal, slack, ecap = ctypes.c_int32(), ctypes.c_int32(), ctypes.c_int32()
         budget = int(os.environ.get("GSAT_PNA_TILE_LDS", "0"))
         if _lib.load().gsat_pna_tile_plan(int(H), budget, ctypes.byref(nominal), ctypes.byref(slack), ctypes.byref(ecap)) != 0:

@@ -38,7 +38,16 @@ for H in (32, 64, 80, 96, 128, 160, 256):
                      a_arr, A, s_arr, 1, 1.0, 1.0, ptr(y), stream())
     g = lambda: call("gsat_pna_bwd", ptr(x), ptr(att), None, ptr(dout), ptr(ix.rowptr_dst), ptr(ix.src_by_dst), ptr(ix.eid_by_dst), N, H,
                      a_arr, A, s_arr, 1, 1.0, 1.0, ptr(dxs), ptr(dmsg), ptr(datt), None, stream())
+    ix.graphs(data.batch, data.num_graphs)
+    tiles = ix.pna_tiles(H)
+    dx = torch.empty(N, H, device=dev)
+    if tiles:
+        td, T, rn, rc, ec, spill = tiles
+        h = lambda: call("gsat_pna_bwd_tiled", ptr(x), ptr(att), ptr(dout), ptr(ix.rowptr_dst), ptr(ix.src_by_dst), ptr(ix.eid_by_dst), ptr(td), T, rn, rc, ec,
+                         ptr(ix.rowptr_src), ptr(ix.slot_dst_of_srcslot), N, E, H, a_arr, A, s_arr, 1, ptr(spill[1:]), ptr(spill[:1]), ptr(dx), ptr(dmsg), ptr(datt), stream())
     fb = 4 * N * H + 8 * A * N * H + 8 * E + 4 * N
     bb = 4 * A * 2 * N * H + 8 * N * H + 4 * E * H + 16 * E + 4 * N
     tf, tb = timeit(f), timeit(g)
-    print(f"H={H:4d}  fwd {tf:7.2f} us {fb / tf / 1e3:7.0f} GB/s   bwd {tb:7.2f} us {bb / tb / 1e3:7.0f} GB/s")
+    cb = 4 * A * 2 * N * H + 8 * N * H + 16 * E + 4 * N          # compulsory bytes of the whole backward
+    tt = timeit(h) if tiles else float("nan")
+    print(f"H={H:4d}  fwd {tf:7.2f} us {fb / tf / 1e3:7.0f} GB/s   bwd_dst (1st of 2 passes) {tb:7.2f} us {bb / tb / 1e3:7.0f} GB/s   tiled bwd (whole) {tt:7.2f} us {cb / tt / 1e3:7.0f} GB/s")
