@@ -71,10 +71,24 @@ int aggr_sum_fwd_impl(hipStream_t stream, const float* x, const float* self_rows
 constexpr int WAVE = 64;
 
 // sum over the `width` consecutive lanes of an aligned lane group (width = power of two <= 64)
+// One cross-lane step of a reduction as a DPP operand modifier of the add (no LDS crossbar round trip): v + v[lane permuted by CTRL]
+template <int CTRL> __device__ __forceinline__ float dpp_add(float v) {
+    const int t = __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xF, 0xF, true);
+    return v + __builtin_bit_cast(float, t);
+}
+
+// sum over the WIDTH consecutive lanes of an aligned lane group; power-of-two widths leave the total in EVERY lane of the group.
+// Steps inside a 16-lane row are DPP adds (quad permutes, half-row and row mirrors: ~1 VALU op each); the 16 <-> 16 step is one
+// ds_swizzle, the 32 <-> 32 step one ds_bpermute -- the five dependent ds_bpermute round trips of a shuffle butterfly were the
+// longest latency chain of the per-edge loops (PNA backward 76 -> ~70 us at C3).
 template <int WIDTH> __device__ __forceinline__ float group_sum(float v) {
     if constexpr ((WIDTH & (WIDTH - 1)) == 0) {
-#pragma unroll
-        for (int o = WIDTH / 2; o > 0; o >>= 1) v += __shfl_xor(v, o, WIDTH);
+        if constexpr (WIDTH >= 2) v = dpp_add<0xB1>(v);            // quad_perm [1,0,3,2]: lane ^ 1
+        if constexpr (WIDTH >= 4) v = dpp_add<0x4E>(v);            // quad_perm [2,3,0,1]: lane ^ 2
+        if constexpr (WIDTH >= 8) v = dpp_add<0x141>(v);           // row_half_mirror: the other quad of the 8-lane half row
+        if constexpr (WIDTH >= 16) v = dpp_add<0x140>(v);          // row_mirror: the other half of the 16-lane row
+        if constexpr (WIDTH >= 32) v += __builtin_bit_cast(float, __builtin_amdgcn_ds_swizzle(__builtin_bit_cast(int, v), 0x401F));   // lane ^ 16
+        if constexpr (WIDTH >= 64) v += __shfl_xor(v, 32, 64);
     } else {
         // lane groups that are not a power of two wide (20 lanes = 80 channels, three groups per wave): a shift-down tree over the
         // group's lanes; only lane 0 of the group holds the full sum (which is all the callers read)
