@@ -7,6 +7,8 @@
 
 namespace gsat {
 
+constexpr int64_t GSAT_COUNTING_MAX_KEYS = 1 << 20;     // rocPRIM's own switch from merge sort to Onesweep
+
 static thread_local char g_err[512] = {0};
 void set_error(const char* fmt, ...) {
     va_list ap;
@@ -200,6 +202,130 @@ __global__ void k_pair_gather(const int64_t* __restrict__ ei, const int32_t* __r
     slot_dst_of_srcslot[k - E] = lo;
 }
 
+// ---- the same two CSRs by counting instead of sorting (batches up to GSAT_COUNTING_MAX_KEYS keys) ---------------------------------
+// Below 1 M items rocPRIM's radix_sort_pairs is an iterated merge sort: 16 dependent launches (~80 us) for a molecule batch's 2e5 keys,
+// the largest single piece of the per-batch bookkeeping (its Onesweep alternative zeroes its histograms with hipMemsetAsync, which a
+// captured graph on ROCm 7.2 does not order against the neighbouring replay).  The keys are row numbers, so:
+//   count   cnt[key]++                                   (integer atomics: the totals do not depend on the order)
+//   scan    first[key] = exclusive sum of cnt            (rocPRIM, two launches)
+//   place   slot[first[key] + --cnt[key]] = edge id      (arbitrary order inside a row)
+//   order   every row's edge ids ascending               (= the stable order of the sort): rank sort by one thread for rows of <= 32
+//           entries, listed rows (longer) by a workgroup each: bitonic network in LDS per 4096-entry chunk, chunks merged by rank
+// The result is the unique (row, edge id) order, bit-identical to the sort's, in 7 launches.
+constexpr int COUNT_SHORT_ROW = 32;
+constexpr int COUNT_CHUNK = 4096;
+constexpr int COUNT_LONG_BLOCK = 256;
+
+__global__ void k_pair_count(const int64_t* __restrict__ ei, int64_t E, int64_t N, int32_t* __restrict__ cnt,
+                             int32_t* __restrict__ src32, int32_t* __restrict__ dst32, int32_t* err) {
+    int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= E) return;
+    int64_t s = ei[e], d = ei[E + e];
+    if (s < 0 || s >= N) { atomicAdd(err, 1); s = N - 1; }
+    if (d < 0 || d >= N) { atomicAdd(err, 1); d = N - 1; }
+    atomicAdd(&cnt[d], 1);
+    atomicAdd(&cnt[N + s], 1);
+    if (src32) src32[e] = (int32_t)s;
+    if (dst32) dst32[e] = (int32_t)d;
+}
+
+__global__ void k_pair_place(const int64_t* __restrict__ ei, int64_t E, int64_t N, const int32_t* __restrict__ first,
+                             int32_t* __restrict__ cnt, int32_t* __restrict__ slot) {
+    int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= E) return;
+    int64_t s = ei[e], d = ei[E + e];
+    s = (s < 0 || s >= N) ? N - 1 : s;
+    d = (d < 0 || d >= N) ? N - 1 : d;
+    slot[first[d] + atomicSub(&cnt[d], 1) - 1] = (int32_t)e;
+    slot[first[N + s] + atomicSub(&cnt[N + s], 1) - 1] = (int32_t)e;
+}
+
+// one thread per key row (2N rows + the closing entry): row pointers of both CSRs, short rows ordered, long rows listed
+__global__ void k_pair_order_short(const int32_t* __restrict__ first, int64_t E, int64_t N, const int32_t* __restrict__ slot,
+                                   int32_t* __restrict__ perm, int32_t* __restrict__ rowptr_dst, int32_t* __restrict__ rowptr_src,
+                                   int32_t* __restrict__ long_rows, int32_t* __restrict__ long_count) {
+    int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (k > 2 * N) return;
+    const int beg = first[k];
+    if (k <= N) rowptr_dst[k] = beg;
+    if (k >= N) rowptr_src[k - N] = beg - (int32_t)E;
+    if (k == 2 * N) return;
+    const int end = first[k + 1], deg = end - beg;
+    if (deg > COUNT_SHORT_ROW) {
+        long_rows[atomicAdd(long_count, 1)] = (int32_t)k;        // order of the list is irrelevant: every listed row is ordered on its own
+        return;
+    }
+    for (int i = beg; i < end; ++i) {
+        const int v = slot[i];
+        int r = 0;
+        for (int j = beg; j < end; ++j) r += slot[j] < v;
+        perm[beg + r] = v;
+    }
+}
+
+__global__ __launch_bounds__(COUNT_LONG_BLOCK) void k_pair_order_long(const int32_t* __restrict__ first, int32_t* __restrict__ slot,
+                                                                       int32_t* __restrict__ perm, const int32_t* __restrict__ long_rows,
+                                                                       const int32_t* __restrict__ long_count) {
+    __shared__ int32_t buf[COUNT_CHUNK];
+    const int nlong = *long_count;
+    for (int q = blockIdx.x; q < nlong; q += gridDim.x) {
+        const int k = long_rows[q];
+        const int beg = first[k], end = first[k + 1], deg = end - beg;
+        const int nchunks = (deg + COUNT_CHUNK - 1) / COUNT_CHUNK;
+        for (int c = 0; c < nchunks; ++c) {
+            const int cb = beg + c * COUNT_CHUNK, len = min(COUNT_CHUNK, end - cb);
+            int p2 = 64;
+            while (p2 < len) p2 <<= 1;
+            for (int i = threadIdx.x; i < p2; i += COUNT_LONG_BLOCK) buf[i] = i < len ? slot[cb + i] : 0x7fffffff;
+            __syncthreads();
+            for (int size = 2; size <= p2; size <<= 1)
+                for (int stride = size >> 1; stride > 0; stride >>= 1) {
+                    for (int t = threadIdx.x; t < (p2 >> 1); t += COUNT_LONG_BLOCK) {
+                        const int lo = 2 * t - (t & (stride - 1)), hi = lo + stride;
+                        const bool up = (lo & size) == 0;
+                        const int a = buf[lo], b = buf[hi];
+                        if ((a > b) == up) { buf[lo] = b; buf[hi] = a; }
+                    }
+                    __syncthreads();
+                }
+            // a single chunk is final; several chunks go back to slot[] chunk-sorted for the rank merge below
+            int32_t* outp = nchunks == 1 ? perm : slot;
+            for (int i = threadIdx.x; i < len; i += COUNT_LONG_BLOCK) outp[cb + i] = buf[i];
+            __syncthreads();
+        }
+        if (nchunks == 1) continue;
+        // edge ids are distinct: final position = own position in its chunk + the number of smaller ids in every other chunk
+        for (int i = threadIdx.x; i < deg; i += COUNT_LONG_BLOCK) {
+            const int v = slot[beg + i], own = i / COUNT_CHUNK;
+            int r = i - own * COUNT_CHUNK;
+            for (int c = 0; c < nchunks; ++c) {
+                if (c == own) continue;
+                const int32_t* base = slot + beg + c * COUNT_CHUNK;
+                int lo = 0, hi = min(COUNT_CHUNK, deg - c * COUNT_CHUNK);
+                while (lo < hi) {
+                    const int mid = (lo + hi) >> 1;
+                    if (base[mid] < v) lo = mid + 1; else hi = mid;
+                }
+                r += lo;
+            }
+            perm[beg + r] = v;
+        }
+        __syncthreads();
+    }
+}
+
+static size_t count_scan_temp_bytes(int64_t n) {
+    size_t tb = 0;
+    int32_t* p = nullptr;
+    (void)rocprim::exclusive_scan(nullptr, tb, p, p, 0, (size_t)(2 * n + 1), rocprim::plus<int>(), (hipStream_t)0);
+    return align_up(tb, 256) + 256;
+}
+
+static bool counting_build(int64_t E) {
+    static const int on = [] { const char* e = getenv("GSAT_CSR_COUNTING"); return e ? atoi(e) : 1; }();
+    return on && 2 * E <= GSAT_COUNTING_MAX_KEYS;
+}
+
 struct ChunkCount2 {     // ChunkCount over the rows of both CSRs laid end to end: [0, N] by-destination, [N+1, 2N+1] by-source
     const int32_t* rp_dst;
     const int32_t* rp_src;
@@ -329,8 +455,8 @@ int gsat_reverse_edge_perm(const int64_t* edge_index, int64_t E, int64_t N, int3
 
 size_t gsat_csr_pair_workspace_bytes(int64_t E, int64_t N) {
     const size_t e2 = (size_t)(E > 0 ? 2 * E : 2), n2 = (size_t)(N > 0 ? 2 * N + 2 : 2);
-    return 4 * align_up(e2 * 4, 256) + align_up((size_t)(E > 0 ? E : 1) * 4, 256) + align_up(n2 * 4, 256) + sort_temp_bytes<uint32_t>(2 * E) +
-           chunk2_scan_temp_bytes(N);
+    return 4 * align_up(e2 * 4, 256) + align_up((size_t)(E > 0 ? E : 1) * 4, 256) + 3 * align_up(n2 * 4, 256) +
+           std::max(sort_temp_bytes<uint32_t>(2 * E), count_scan_temp_bytes(N)) + chunk2_scan_temp_bytes(N);
 }
 
 int gsat_build_csr_pair(const int64_t* edge_index, int64_t E, int64_t N, int32_t* rowptr_dst, int32_t* src_by_dst, int32_t* eid_by_dst,
@@ -356,17 +482,36 @@ int gsat_build_csr_pair(const int64_t* edge_index, int64_t E, int64_t N, int32_t
     int32_t* ids = ar.take<int32_t>(2 * E);
     int32_t* perm = ar.take<int32_t>(2 * E);
     int32_t* scan = ar.take<int32_t>(2 * N + 2);
-    size_t tb = sort_temp_bytes<uint32_t>(2 * E), tc = chunk2_scan_temp_bytes(N);
+    int32_t* cnt = ar.take<int32_t>(2 * N + 2);          // counting build: [0, 2N) row counts, [2N] = 0 closes the scan, [2N+1] = long rows listed
+    int32_t* first = ar.take<int32_t>(2 * N + 2);
+    const bool counting = counting_build(E);
+    size_t tb = std::max(sort_temp_bytes<uint32_t>(2 * E), count_scan_temp_bytes(N)), tc = chunk2_scan_temp_bytes(N);
     char* temp = ar.take<char>(tb);
     char* temp2 = ar.take<char>(tc);
     GSAT_REQUIRE(ar.ok() && temp && temp2, GSAT_ERR_WORKSPACE, "gsat_build_csr_pair: workspace %zu < %zu", ws_bytes, ar.off);
     const int B = 256;
-    k_make_pair_keys<<<ceil_div(E, B), B, 0, stream>>>(edge_index, E, N, keys_in, ids, src32, dst32, err_flag);
-    GSAT_LAUNCH_CHECK();
-    const int end_bit = bits_for((uint64_t)(2 * N - 1));
-    GSAT_CHECK_HIP(rocprim::radix_sort_pairs(temp, tb, keys_in, keys_out, ids, perm, (size_t)(2 * E), 0, (unsigned)end_bit, stream));
-    k_pair_rowptrs<<<ceil_div(2 * N + 2, B), B, 0, stream>>>(keys_out, E, N, rowptr_dst, rowptr_src);
-    GSAT_LAUNCH_CHECK();
+    if (counting) {
+        int32_t* slot = ids;                             // [2E] edge ids grouped by row, unordered inside a row
+        int32_t* long_rows = reinterpret_cast<int32_t*>(keys_in);      // [<= 2N rows longer than COUNT_SHORT_ROW <= 2E / 33 entries]
+        GSAT_CHECK_HIP(gsat::zero_async(cnt, (size_t)(2 * N + 2) * sizeof(int32_t), stream));
+        k_pair_count<<<ceil_div(E, B), B, 0, stream>>>(edge_index, E, N, cnt, src32, dst32, err_flag);
+        GSAT_LAUNCH_CHECK();
+        size_t ts = count_scan_temp_bytes(N);
+        GSAT_CHECK_HIP(rocprim::exclusive_scan(temp, ts, cnt, first, 0, (size_t)(2 * N + 1), rocprim::plus<int>(), stream));
+        k_pair_place<<<ceil_div(E, B), B, 0, stream>>>(edge_index, E, N, first, cnt, slot);
+        GSAT_LAUNCH_CHECK();
+        k_pair_order_short<<<ceil_div(2 * N + 1, B), B, 0, stream>>>(first, E, N, slot, perm, rowptr_dst, rowptr_src, long_rows, cnt + 2 * N + 1);
+        GSAT_LAUNCH_CHECK();
+        k_pair_order_long<<<256, COUNT_LONG_BLOCK, 0, stream>>>(first, slot, perm, long_rows, cnt + 2 * N + 1);
+        GSAT_LAUNCH_CHECK();
+    } else {
+        k_make_pair_keys<<<ceil_div(E, B), B, 0, stream>>>(edge_index, E, N, keys_in, ids, src32, dst32, err_flag);
+        GSAT_LAUNCH_CHECK();
+        const int end_bit = bits_for((uint64_t)(2 * N - 1));
+        GSAT_CHECK_HIP(rocprim::radix_sort_pairs(temp, tb, keys_in, keys_out, ids, perm, (size_t)(2 * E), 0, (unsigned)end_bit, stream));
+        k_pair_rowptrs<<<ceil_div(2 * N + 2, B), B, 0, stream>>>(keys_out, E, N, rowptr_dst, rowptr_src);
+        GSAT_LAUNCH_CHECK();
+    }
     k_pair_gather<<<ceil_div(2 * E, B), B, 0, stream>>>(edge_index, perm, E, N, rowptr_dst, src_by_dst, eid_by_dst, dst_by_src, eid_by_src,
                                                         slot_dst_of_srcslot);
     GSAT_LAUNCH_CHECK();

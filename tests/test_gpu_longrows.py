@@ -139,3 +139,27 @@ def test_extractor_with_sliced_segments(dev):
         close(ed.grad, r32["demb"], ref64=r64["demb"], what="demb")
         for k, p in ext.named_parameters():
             close(p.grad, r32[k], ref64=r64[k], what=k)
+
+
+@pytest.mark.parametrize("hub_deg", [40, 3000, 4096, 4097, 20000])
+def test_counting_csr_build_orders_long_rows(dev, hub_deg):
+    """Batches below 2^20 keys build both CSRs by counting + per-row ordering (bookkeeping.hip): rows of <= 32 entries by one thread,
+    longer ones by a workgroup (one bitonic chunk of 4096, or several chunks merged by rank).  Bit-exact vs a stable argsort."""
+    from dp_gsat_amd.graph_index import BatchIndex
+    rng = np.random.default_rng(hub_deg)
+    N = hub_deg + 500
+    leaves = rng.permutation(np.arange(1, N))[:hub_deg]
+    src = np.concatenate([leaves, np.zeros(hub_deg, np.int64), rng.integers(0, N, 3000)])
+    dst = np.concatenate([np.zeros(hub_deg, np.int64), leaves, rng.integers(0, N, 3000)])
+    order = rng.permutation(src.size)              # hub edges scattered over the whole edge list
+    ei = torch.from_numpy(np.stack([src[order], dst[order]]))
+    ix = BatchIndex(ei.to(dev), N)
+    s, d = ei[0].numpy(), ei[1].numpy()
+    for rows, other, rp, col, eid in ((d, s, ix.rowptr_dst, ix.src_by_dst, ix.eid_by_dst), (s, d, ix.rowptr_src, ix.dst_by_src, ix.eid_by_src)):
+        perm = np.argsort(rows, kind="stable")
+        assert np.array_equal(rp.cpu().numpy(), np.concatenate([[0], np.cumsum(np.bincount(rows, minlength=N))]))
+        assert np.array_equal(eid.cpu().numpy(), perm)
+        assert np.array_equal(col.cpu().numpy(), other[perm])
+    inv = np.empty(src.size, np.int64)
+    inv[ix.eid_by_dst.cpu().numpy()] = np.arange(src.size)
+    assert np.array_equal(ix.slot_dst_of_srcslot.cpu().numpy(), inv[ix.eid_by_src.cpu().numpy()])
