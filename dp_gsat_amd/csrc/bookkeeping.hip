@@ -229,28 +229,36 @@ __global__ void k_pair_count(const int64_t* __restrict__ ei, int64_t E, int64_t 
     if (dst32) dst32[e] = (int32_t)d;
 }
 
-__global__ void k_pair_place(const int64_t* __restrict__ ei, int64_t E, int64_t N, const int32_t* __restrict__ first,
+__global__ void k_pair_place(const int64_t* __restrict__ ei, int64_t E, int64_t N, const int64_t* __restrict__ first,
                              int32_t* __restrict__ cnt, int32_t* __restrict__ slot) {
     int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (e >= E) return;
     int64_t s = ei[e], d = ei[E + e];
     s = (s < 0 || s >= N) ? N - 1 : s;
     d = (d < 0 || d >= N) ? N - 1 : d;
-    slot[first[d] + atomicSub(&cnt[d], 1) - 1] = (int32_t)e;
-    slot[first[N + s] + atomicSub(&cnt[N + s], 1) - 1] = (int32_t)e;
+    slot[(int32_t)first[d] + atomicSub(&cnt[d], 1) - 1] = (int32_t)e;
+    slot[(int32_t)first[N + s] + atomicSub(&cnt[N + s], 1) - 1] = (int32_t)e;
 }
 
-// one thread per key row (2N rows + the closing entry): row pointers of both CSRs, short rows ordered, long rows listed
-__global__ void k_pair_order_short(const int32_t* __restrict__ first, int64_t E, int64_t N, const int32_t* __restrict__ slot,
+// one thread per key row (2N rows + the closing entry): row and hub-chunk pointers of both CSRs, short rows ordered, long rows listed
+__global__ void k_pair_order_short(const int64_t* __restrict__ first, int64_t E, int64_t N, const int32_t* __restrict__ slot,
                                    int32_t* __restrict__ perm, int32_t* __restrict__ rowptr_dst, int32_t* __restrict__ rowptr_src,
+                                   int32_t* __restrict__ chunk_ptr_dst, int32_t* __restrict__ chunk_ptr_src, int32_t* __restrict__ status,
                                    int32_t* __restrict__ long_rows, int32_t* __restrict__ long_count) {
     int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (k > 2 * N) return;
-    const int beg = first[k];
-    if (k <= N) rowptr_dst[k] = beg;
-    if (k >= N) rowptr_src[k - N] = beg - (int32_t)E;
+    const int64_t f = first[k];
+    const int beg = (int32_t)f, chunks = (int32_t)(f >> 32);
+    if (k <= N) { rowptr_dst[k] = beg; chunk_ptr_dst[k] = chunks; }
+    if (k == N) status[1] = chunks;                      // hub-chunk totals next to the range-error counter: one host read gets all
+    if (k >= N) {
+        const int c0 = (int32_t)(first[N] >> 32);
+        rowptr_src[k - N] = beg - (int32_t)E;
+        chunk_ptr_src[k - N] = chunks - c0;
+        if (k == 2 * N) status[2] = chunks - c0;
+    }
     if (k == 2 * N) return;
-    const int end = first[k + 1], deg = end - beg;
+    const int end = (int32_t)first[k + 1], deg = end - beg;
     if (deg > COUNT_SHORT_ROW) {
         long_rows[atomicAdd(long_count, 1)] = (int32_t)k;        // order of the list is irrelevant: every listed row is ordered on its own
         return;
@@ -263,14 +271,14 @@ __global__ void k_pair_order_short(const int32_t* __restrict__ first, int64_t E,
     }
 }
 
-__global__ __launch_bounds__(COUNT_LONG_BLOCK) void k_pair_order_long(const int32_t* __restrict__ first, int32_t* __restrict__ slot,
+__global__ __launch_bounds__(COUNT_LONG_BLOCK) void k_pair_order_long(const int64_t* __restrict__ first, int32_t* __restrict__ slot,
                                                                        int32_t* __restrict__ perm, const int32_t* __restrict__ long_rows,
                                                                        const int32_t* __restrict__ long_count) {
     __shared__ int32_t buf[COUNT_CHUNK];
     const int nlong = *long_count;
     for (int q = blockIdx.x; q < nlong; q += gridDim.x) {
         const int k = long_rows[q];
-        const int beg = first[k], end = first[k + 1], deg = end - beg;
+        const int beg = (int32_t)first[k], end = (int32_t)first[k + 1], deg = end - beg;
         const int nchunks = (deg + COUNT_CHUNK - 1) / COUNT_CHUNK;
         for (int c = 0; c < nchunks; ++c) {
             const int cb = beg + c * COUNT_CHUNK, len = min(COUNT_CHUNK, end - cb);
@@ -314,10 +322,22 @@ __global__ __launch_bounds__(COUNT_LONG_BLOCK) void k_pair_order_long(const int3
     }
 }
 
+// scanned value of key row k: entries in the low word, hub chunks (ChunkCount's rule) in the high word -- one scan yields the row
+// pointers and the chunk pointers of both CSRs
+struct CountAndChunks {
+    const int32_t* cnt;
+    __host__ __device__ int64_t operator()(int k) const {
+        const int deg = cnt[k];
+        const int64_t chunks = deg > GSAT_LONG_ROW_EDGES ? (deg + GSAT_LONG_ROW_EDGES - 1) / GSAT_LONG_ROW_EDGES : 0;
+        return (int64_t)deg + (chunks << 32);
+    }
+};
+
 static size_t count_scan_temp_bytes(int64_t n) {
     size_t tb = 0;
-    int32_t* p = nullptr;
-    (void)rocprim::exclusive_scan(nullptr, tb, p, p, 0, (size_t)(2 * n + 1), rocprim::plus<int>(), (hipStream_t)0);
+    auto in = rocprim::make_transform_iterator(rocprim::make_counting_iterator<int>(0), CountAndChunks{nullptr});
+    int64_t* p = nullptr;
+    (void)rocprim::exclusive_scan(nullptr, tb, in, p, (int64_t)0, (size_t)(2 * n + 1), rocprim::plus<int64_t>(), (hipStream_t)0);
     return align_up(tb, 256) + 256;
 }
 
@@ -455,7 +475,7 @@ int gsat_reverse_edge_perm(const int64_t* edge_index, int64_t E, int64_t N, int3
 
 size_t gsat_csr_pair_workspace_bytes(int64_t E, int64_t N) {
     const size_t e2 = (size_t)(E > 0 ? 2 * E : 2), n2 = (size_t)(N > 0 ? 2 * N + 2 : 2);
-    return 4 * align_up(e2 * 4, 256) + align_up((size_t)(E > 0 ? E : 1) * 4, 256) + 3 * align_up(n2 * 4, 256) +
+    return 4 * align_up(e2 * 4, 256) + align_up((size_t)(E > 0 ? E : 1) * 4, 256) + 4 * align_up(n2 * 4, 256) +
            std::max(sort_temp_bytes<uint32_t>(2 * E), count_scan_temp_bytes(N)) + chunk2_scan_temp_bytes(N);
 }
 
@@ -483,7 +503,7 @@ int gsat_build_csr_pair(const int64_t* edge_index, int64_t E, int64_t N, int32_t
     int32_t* perm = ar.take<int32_t>(2 * E);
     int32_t* scan = ar.take<int32_t>(2 * N + 2);
     int32_t* cnt = ar.take<int32_t>(2 * N + 2);          // counting build: [0, 2N) row counts, [2N] = 0 closes the scan, [2N+1] = long rows listed
-    int32_t* first = ar.take<int32_t>(2 * N + 2);
+    int64_t* first = ar.take<int64_t>(2 * N + 2);          // (entries, hub chunks) before each key row
     const bool counting = counting_build(E);
     size_t tb = std::max(sort_temp_bytes<uint32_t>(2 * E), count_scan_temp_bytes(N)), tc = chunk2_scan_temp_bytes(N);
     char* temp = ar.take<char>(tb);
@@ -497,10 +517,12 @@ int gsat_build_csr_pair(const int64_t* edge_index, int64_t E, int64_t N, int32_t
         k_pair_count<<<ceil_div(E, B), B, 0, stream>>>(edge_index, E, N, cnt, src32, dst32, err_flag);
         GSAT_LAUNCH_CHECK();
         size_t ts = count_scan_temp_bytes(N);
-        GSAT_CHECK_HIP(rocprim::exclusive_scan(temp, ts, cnt, first, 0, (size_t)(2 * N + 1), rocprim::plus<int>(), stream));
+        auto cin = rocprim::make_transform_iterator(rocprim::make_counting_iterator<int>(0), CountAndChunks{cnt});
+        GSAT_CHECK_HIP(rocprim::exclusive_scan(temp, ts, cin, first, (int64_t)0, (size_t)(2 * N + 1), rocprim::plus<int64_t>(), stream));
         k_pair_place<<<ceil_div(E, B), B, 0, stream>>>(edge_index, E, N, first, cnt, slot);
         GSAT_LAUNCH_CHECK();
-        k_pair_order_short<<<ceil_div(2 * N + 1, B), B, 0, stream>>>(first, E, N, slot, perm, rowptr_dst, rowptr_src, long_rows, cnt + 2 * N + 1);
+        k_pair_order_short<<<ceil_div(2 * N + 1, B), B, 0, stream>>>(first, E, N, slot, perm, rowptr_dst, rowptr_src, chunk_ptr_dst, chunk_ptr_src,
+                                                                       err_flag, long_rows, cnt + 2 * N + 1);
         GSAT_LAUNCH_CHECK();
         k_pair_order_long<<<256, COUNT_LONG_BLOCK, 0, stream>>>(first, slot, perm, long_rows, cnt + 2 * N + 1);
         GSAT_LAUNCH_CHECK();
@@ -515,6 +537,7 @@ int gsat_build_csr_pair(const int64_t* edge_index, int64_t E, int64_t N, int32_t
     k_pair_gather<<<ceil_div(2 * E, B), B, 0, stream>>>(edge_index, perm, E, N, rowptr_dst, src_by_dst, eid_by_dst, dst_by_src, eid_by_src,
                                                         slot_dst_of_srcslot);
     GSAT_LAUNCH_CHECK();
+    if (counting) return GSAT_OK;                        // chunk pointers came out of the same scan
     auto in = rocprim::make_transform_iterator(rocprim::make_counting_iterator<int>(0), ChunkCount2{rowptr_dst, rowptr_src, (int)N});
     GSAT_CHECK_HIP(rocprim::exclusive_scan(temp2, tc, in, scan, 0, (size_t)(2 * N + 2), rocprim::plus<int>(), stream));
     k_split_chunk_ptrs<<<ceil_div(N + 1, B), B, 0, stream>>>(scan, N, chunk_ptr_dst, chunk_ptr_src, err_flag);
