@@ -19,6 +19,7 @@ constexpr float IN_EPS = 1e-5f;
 constexpr int SB = 256;          // threads per block in the segmented kernels: 16 row slots x 16 lanes
 constexpr int SB_LANES = 16;     // lanes per row slot, one float4 each -> 64 channels per block
 constexpr int SB_SLOTS = 16;
+constexpr int SB_RC = 4;         // rows per slot kept in registers across the passes of the segmented kernels
 
 // row-major C[M,N] = alpha(=1) * op(A) op(B) + beta(0|1) * C through the hand-written MFMA GEMM (gemm.hip).
 // ta: A is given as [K,M]; tb: B is given as [N,K] (nn.Linear weight layout).
@@ -152,23 +153,46 @@ __global__ __launch_bounds__(SB) void k_seg_stats(PreAct<EDGE> pre, const int32_
     const bool on = c < C;
     const int beg = seg_ptr[g], end = seg_ptr[g + 1];
     const float inv_n = 1.f / (float)max(end - beg, 1);
+    // the first SB_RC rows of every slot stay in registers across the passes (segments of <= 64 rows -- every molecule graph -- make ONE
+    // trip to memory instead of three dependent ones); longer segments re-read their tail, L2-hot, as before.  Same summation order.
+    float4 hc[SB_RC];
+    int mc[SB_RC];
+#pragma unroll
+    for (int i = 0; i < SB_RC; ++i) {
+        const int r = beg + slot + i * SB_SLOTS;
+        mc[i] = (r < end) ? (order ? order[r] : r) : -1;
+    }
+#pragma unroll
+    for (int i = 0; i < SB_RC; ++i) hc[i] = (on && mc[i] >= 0) ? pre.load(mc[i], c) : f4zero();
+    const int rest = beg + slot + SB_RC * SB_SLOTS;
     float4 acc = f4zero();
-    if (on)
-        for (int r = beg + slot; r < end; r += SB_SLOTS) {
+    if (on) {
+#pragma unroll
+        for (int i = 0; i < SB_RC; ++i)
+            if (mc[i] >= 0) { acc.x += hc[i].x; acc.y += hc[i].y; acc.z += hc[i].z; acc.w += hc[i].w; }
+        for (int r = rest; r < end; r += SB_SLOTS) {
             float4 h = pre.load(order ? order[r] : r, c);
             acc.x += h.x; acc.y += h.y; acc.z += h.z; acc.w += h.w;
         }
+    }
     float4 tot = slot_reduce(acc, sm, slot, lane);
     if (slot == 0) bc[lane] = make_float4(tot.x * inv_n, tot.y * inv_n, tot.z * inv_n, tot.w * inv_n);
     __syncthreads();
     const float4 mu = bc[lane];
     acc = f4zero();
-    if (on)
-        for (int r = beg + slot; r < end; r += SB_SLOTS) {
+    if (on) {
+#pragma unroll
+        for (int i = 0; i < SB_RC; ++i)
+            if (mc[i] >= 0) {
+                float dx = hc[i].x - mu.x, dy = hc[i].y - mu.y, dz = hc[i].z - mu.z, dw = hc[i].w - mu.w;
+                acc.x = fmaf(dx, dx, acc.x); acc.y = fmaf(dy, dy, acc.y); acc.z = fmaf(dz, dz, acc.z); acc.w = fmaf(dw, dw, acc.w);
+            }
+        for (int r = rest; r < end; r += SB_SLOTS) {
             float4 h = pre.load(order ? order[r] : r, c);
             float dx = h.x - mu.x, dy = h.y - mu.y, dz = h.z - mu.z, dw = h.w - mu.w;
             acc.x = fmaf(dx, dx, acc.x); acc.y = fmaf(dy, dy, acc.y); acc.z = fmaf(dz, dz, acc.z); acc.w = fmaf(dw, dw, acc.w);
         }
+    }
     tot = slot_reduce(acc, sm, slot, lane);
     float4 rs = make_float4(1.f / sqrtf(tot.x * inv_n + IN_EPS), 1.f / sqrtf(tot.y * inv_n + IN_EPS),
                             1.f / sqrtf(tot.z * inv_n + IN_EPS), 1.f / sqrtf(tot.w * inv_n + IN_EPS));
@@ -181,8 +205,18 @@ __global__ __launch_bounds__(SB) void k_seg_stats(PreAct<EDGE> pre, const int32_
         __syncthreads();
         rs = bc[lane];
         const float sc = (training && p > 0.f) ? 1.f / (1.f - p) : 1.f;
-        if (on)
-            for (int r = beg + slot; r < end; r += SB_SLOTS) {
+        if (on) {
+#pragma unroll
+            for (int i = 0; i < SB_RC; ++i)
+                if (mc[i] >= 0) {
+                    const int m = mc[i];
+                    const float4 h = hc[i];
+                    const float4 k = keep4(mask, seed, layer, m, c, C, p, training != 0);
+                    st4(act_out + (size_t)m * C + c,
+                        make_float4(fmaxf((h.x - mu.x) * rs.x, 0.f) * k.x * sc, fmaxf((h.y - mu.y) * rs.y, 0.f) * k.y * sc,
+                                    fmaxf((h.z - mu.z) * rs.z, 0.f) * k.z * sc, fmaxf((h.w - mu.w) * rs.w, 0.f) * k.w * sc));
+                }
+            for (int r = rest; r < end; r += SB_SLOTS) {
                 const int m = order ? order[r] : r;
                 const float4 h = pre.load(m, c);
                 const float4 k = keep4(mask, seed, layer, m, c, C, p, training != 0);
@@ -190,6 +224,7 @@ __global__ __launch_bounds__(SB) void k_seg_stats(PreAct<EDGE> pre, const int32_
                     make_float4(fmaxf((h.x - mu.x) * rs.x, 0.f) * k.x * sc, fmaxf((h.y - mu.y) * rs.y, 0.f) * k.y * sc,
                                 fmaxf((h.z - mu.z) * rs.z, 0.f) * k.z * sc, fmaxf((h.w - mu.w) * rs.w, 0.f) * k.w * sc));
             }
+        }
     }
 }
 
@@ -291,21 +326,48 @@ __global__ __launch_bounds__(SB) void k_head_bwd_stats(const float* __restrict__
     const float sc = (training && p > 0.f) ? 1.f / (1.f - p) : 1.f;
     PreAct<false> pre{h2, nullptr, b2, nullptr, nullptr, C};
     float4 a1 = f4zero(), a2 = f4zero(), a3 = f4zero();
+    // rows, keep factors and dz of the first SB_RC rows per slot stay in registers for the APPLY pass (see k_seg_stats)
+    float4 hc[SB_RC], kc[SB_RC];
+    float dc[SB_RC];
+    int mc[SB_RC];
+#pragma unroll
+    for (int i = 0; i < SB_RC; ++i) {
+        const int r = beg + slot + i * SB_SLOTS;
+        mc[i] = (r < end && on) ? (order ? order[r] : r) : -1;
+    }
+#pragma unroll
+    for (int i = 0; i < SB_RC; ++i) {
+        hc[i] = mc[i] >= 0 ? pre.load(mc[i], c) : f4zero();
+        dc[i] = mc[i] >= 0 ? dz[mc[i]] : 0.f;
+        kc[i] = mc[i] >= 0 ? keep4(mask, seed, 2, mc[i], c, C, p, training != 0) : f4zero();
+    }
+    const int rest = beg + slot + SB_RC * SB_SLOTS;
+    float4 mu = f4zero(), rs = f4zero(), w = f4zero();
+#define GSAT_HEAD_ROW(H4, K4, D)                                                                                                   \
+    const float4 y = make_float4(((H4).x - mu.x) * rs.x, ((H4).y - mu.y) * rs.y, ((H4).z - mu.z) * rs.z, ((H4).w - mu.w) * rs.w);    \
+    const float4 dy = make_float4(y.x > 0.f ? (D) * w.x * (K4).x * sc : 0.f, y.y > 0.f ? (D) * w.y * (K4).y * sc : 0.f,             \
+                                  y.z > 0.f ? (D) * w.z * (K4).z * sc : 0.f, y.w > 0.f ? (D) * w.w * (K4).w * sc : 0.f);
     if (on) {
-        const float4 mu = ld4(mean + (size_t)g * C + c), rs = ld4(rstd + (size_t)g * C + c), w = ld4(w3 + c);
-        for (int r = beg + slot; r < end; r += SB_SLOTS) {
+        mu = ld4(mean + (size_t)g * C + c); rs = ld4(rstd + (size_t)g * C + c); w = ld4(w3 + c);
+#define GSAT_HEAD_ACC(H4, K4, D)                                                                                                   \
+        {                                                                                                                          \
+            GSAT_HEAD_ROW(H4, K4, D)                                                                                               \
+            a1.x += dy.x; a1.y += dy.y; a1.z += dy.z; a1.w += dy.w;                                                                \
+            a2.x = fmaf(dy.x, y.x, a2.x); a2.y = fmaf(dy.y, y.y, a2.y); a2.z = fmaf(dy.z, y.z, a2.z); a2.w = fmaf(dy.w, y.w, a2.w); \
+            a3.x = fmaf((D), fmaxf(y.x, 0.f) * (K4).x * sc, a3.x); a3.y = fmaf((D), fmaxf(y.y, 0.f) * (K4).y * sc, a3.y);          \
+            a3.z = fmaf((D), fmaxf(y.z, 0.f) * (K4).z * sc, a3.z); a3.w = fmaf((D), fmaxf(y.w, 0.f) * (K4).w * sc, a3.w);          \
+        }
+#pragma unroll
+        for (int i = 0; i < SB_RC; ++i)
+            if (mc[i] >= 0) GSAT_HEAD_ACC(hc[i], kc[i], dc[i])
+        for (int r = rest; r < end; r += SB_SLOTS) {
             const int m = order ? order[r] : r;
             const float d = dz[m];
-            float4 h = pre.load(m, c);
-            float4 k = keep4(mask, seed, 2, m, c, C, p, training != 0);
-            float4 y = make_float4((h.x - mu.x) * rs.x, (h.y - mu.y) * rs.y, (h.z - mu.z) * rs.z, (h.w - mu.w) * rs.w);
-            float4 dy = make_float4(y.x > 0.f ? d * w.x * k.x * sc : 0.f, y.y > 0.f ? d * w.y * k.y * sc : 0.f,
-                                    y.z > 0.f ? d * w.z * k.z * sc : 0.f, y.w > 0.f ? d * w.w * k.w * sc : 0.f);
-            a1.x += dy.x; a1.y += dy.y; a1.z += dy.z; a1.w += dy.w;
-            a2.x = fmaf(dy.x, y.x, a2.x); a2.y = fmaf(dy.y, y.y, a2.y); a2.z = fmaf(dy.z, y.z, a2.z); a2.w = fmaf(dy.w, y.w, a2.w);
-            a3.x = fmaf(d, fmaxf(y.x, 0.f) * k.x * sc, a3.x); a3.y = fmaf(d, fmaxf(y.y, 0.f) * k.y * sc, a3.y);
-            a3.z = fmaf(d, fmaxf(y.z, 0.f) * k.z * sc, a3.z); a3.w = fmaf(d, fmaxf(y.w, 0.f) * k.w * sc, a3.w);
+            const float4 h = pre.load(m, c);
+            const float4 k = keep4(mask, seed, 2, m, c, C, p, training != 0);
+            GSAT_HEAD_ACC(h, k, d)
         }
+#undef GSAT_HEAD_ACC
     }
     float4 t1 = slot_reduce(a1, sm, slot, lane);
     float4 t2 = slot_reduce(a2, sm, slot, lane);
@@ -322,19 +384,25 @@ __global__ __launch_bounds__(SB) void k_head_bwd_stats(const float* __restrict__
         __syncthreads();
         if (!on) return;
         const float4 s1 = bc1[lane], s2 = bc2[lane];
-        const float4 mu = ld4(mean + (size_t)g * C + c), rs = ld4(rstd + (size_t)g * C + c), w = ld4(w3 + c);
-        for (int r = beg + slot; r < end; r += SB_SLOTS) {
+#define GSAT_HEAD_OUT(M_, H4, K4, D)                                                                                               \
+        {                                                                                                                          \
+            GSAT_HEAD_ROW(H4, K4, D)                                                                                               \
+            st4(dh2 + (size_t)(M_) * C + c, make_float4(rs.x * (dy.x - s1.x - y.x * s2.x), rs.y * (dy.y - s1.y - y.y * s2.y),        \
+                                                         rs.z * (dy.z - s1.z - y.z * s2.z), rs.w * (dy.w - s1.w - y.w * s2.w)));     \
+        }
+#pragma unroll
+        for (int i = 0; i < SB_RC; ++i)
+            if (mc[i] >= 0) GSAT_HEAD_OUT(mc[i], hc[i], kc[i], dc[i])
+        for (int r = rest; r < end; r += SB_SLOTS) {
             const int m = order ? order[r] : r;
             const float d = dz[m];
             const float4 h = pre.load(m, c);
             const float4 k = keep4(mask, seed, 2, m, c, C, p, training != 0);
-            const float4 y = make_float4((h.x - mu.x) * rs.x, (h.y - mu.y) * rs.y, (h.z - mu.z) * rs.z, (h.w - mu.w) * rs.w);
-            const float4 dy = make_float4(y.x > 0.f ? d * w.x * k.x * sc : 0.f, y.y > 0.f ? d * w.y * k.y * sc : 0.f,
-                                          y.z > 0.f ? d * w.z * k.z * sc : 0.f, y.w > 0.f ? d * w.w * k.w * sc : 0.f);
-            st4(dh2 + (size_t)m * C + c, make_float4(rs.x * (dy.x - s1.x - y.x * s2.x), rs.y * (dy.y - s1.y - y.y * s2.y),
-                                                      rs.z * (dy.z - s1.z - y.z * s2.z), rs.w * (dy.w - s1.w - y.w * s2.w)));
+            GSAT_HEAD_OUT(m, h, k, d)
         }
+#undef GSAT_HEAD_OUT
     }
+#undef GSAT_HEAD_ROW
 }
 
 // dh2[m,c] = rstd2 * (dy2 - S1 - yhat2 * S2)
@@ -381,15 +449,42 @@ __global__ __launch_bounds__(SB) void k_l1_bwd_stats(float* __restrict__ da1, co
     const size_t orow = gridDim.z > 1 ? (size_t)g * gridDim.z + blockIdx.z : (size_t)g;
     const float inv_sc = 1.f / sc;
     float4 s1 = f4zero(), s2 = f4zero();
-    if (on)
-        for (int r = beg + slot; r < end; r += SB_SLOTS) {
+    // da1 / a1 (and, for APPLY, the pre-activation) of the first SB_RC rows per slot stay in registers (see k_seg_stats)
+    float4 dcache[SB_RC], acache[SB_RC], hcache[SB_RC];
+    int mc[SB_RC];
+#pragma unroll
+    for (int i = 0; i < SB_RC; ++i) {
+        const int r = beg + slot + i * SB_SLOTS;
+        mc[i] = (r < end && on) ? (order ? order[r] : r) : -1;
+    }
+#pragma unroll
+    for (int i = 0; i < SB_RC; ++i) {
+        dcache[i] = mc[i] >= 0 ? ld4(da1 + (size_t)mc[i] * C + c) : f4zero();
+        acache[i] = mc[i] >= 0 ? ld4(a1 + (size_t)mc[i] * C + c) : f4zero();
+        if (APPLY) hcache[i] = mc[i] >= 0 ? pre.load(mc[i], c) : f4zero();
+    }
+    const int rest = beg + slot + SB_RC * SB_SLOTS;
+#define GSAT_L1_DY(D4, A4)                                                                                                         \
+    const float4 dy = make_float4((A4).x > 0.f ? (D4).x * sc : 0.f, (A4).y > 0.f ? (D4).y * sc : 0.f,                                \
+                                  (A4).z > 0.f ? (D4).z * sc : 0.f, (A4).w > 0.f ? (D4).w * sc : 0.f);
+#define GSAT_L1_ACC(D4, A4)                                                                                                        \
+    {                                                                                                                              \
+        GSAT_L1_DY(D4, A4)                                                                                                         \
+        s1.x += dy.x; s1.y += dy.y; s1.z += dy.z; s1.w += dy.w;                                                                    \
+        s2.x = fmaf(dy.x, (A4).x * inv_sc, s2.x); s2.y = fmaf(dy.y, (A4).y * inv_sc, s2.y);                                          \
+        s2.z = fmaf(dy.z, (A4).z * inv_sc, s2.z); s2.w = fmaf(dy.w, (A4).w * inv_sc, s2.w);                                          \
+    }
+    if (on) {
+#pragma unroll
+        for (int i = 0; i < SB_RC; ++i)
+            if (mc[i] >= 0) GSAT_L1_ACC(dcache[i], acache[i])
+        for (int r = rest; r < end; r += SB_SLOTS) {
             const int m = order ? order[r] : r;
-            float4 d = ld4(da1 + (size_t)m * C + c), a = ld4(a1 + (size_t)m * C + c);
-            float4 dy = make_float4(a.x > 0.f ? d.x * sc : 0.f, a.y > 0.f ? d.y * sc : 0.f, a.z > 0.f ? d.z * sc : 0.f, a.w > 0.f ? d.w * sc : 0.f);
-            s1.x += dy.x; s1.y += dy.y; s1.z += dy.z; s1.w += dy.w;
-            s2.x = fmaf(dy.x, a.x * inv_sc, s2.x); s2.y = fmaf(dy.y, a.y * inv_sc, s2.y);
-            s2.z = fmaf(dy.z, a.z * inv_sc, s2.z); s2.w = fmaf(dy.w, a.w * inv_sc, s2.w);
+            const float4 d = ld4(da1 + (size_t)m * C + c), a = ld4(a1 + (size_t)m * C + c);
+            GSAT_L1_ACC(d, a)
         }
+    }
+#undef GSAT_L1_ACC
     float4 t1 = slot_reduce(s1, sm, slot, lane);
     float4 t2 = slot_reduce(s2, sm, slot, lane);
     t1 = make_float4(t1.x * inv_n, t1.y * inv_n, t1.z * inv_n, t1.w * inv_n);
@@ -404,16 +499,25 @@ __global__ __launch_bounds__(SB) void k_l1_bwd_stats(float* __restrict__ da1, co
         if (!on) return;
         const float4 q1 = bc1[lane], q2 = bc2[lane];
         const float4 mu = ld4(mean + (size_t)g * C + c), rs = ld4(rstd + (size_t)g * C + c);
-        for (int r = beg + slot; r < end; r += SB_SLOTS) {
+#define GSAT_L1_OUT(M_, H4, D4, A4)                                                                                                \
+        {                                                                                                                          \
+            const float4 y = make_float4(((H4).x - mu.x) * rs.x, ((H4).y - mu.y) * rs.y, ((H4).z - mu.z) * rs.z, ((H4).w - mu.w) * rs.w); \
+            GSAT_L1_DY(D4, A4)                                                                                                     \
+            st4(da1 + (size_t)(M_) * C + c, make_float4(rs.x * (dy.x - q1.x - y.x * q2.x), rs.y * (dy.y - q1.y - y.y * q2.y),        \
+                                                         rs.z * (dy.z - q1.z - y.z * q2.z), rs.w * (dy.w - q1.w - y.w * q2.w)));     \
+        }
+#pragma unroll
+        for (int i = 0; i < SB_RC; ++i)
+            if (mc[i] >= 0) GSAT_L1_OUT(mc[i], hcache[i], dcache[i], acache[i])
+        for (int r = rest; r < end; r += SB_SLOTS) {
             const int m = order ? order[r] : r;
             const float4 h = pre.load(m, c);
-            const float4 y = make_float4((h.x - mu.x) * rs.x, (h.y - mu.y) * rs.y, (h.z - mu.z) * rs.z, (h.w - mu.w) * rs.w);
             const float4 d = ld4(da1 + (size_t)m * C + c), a = ld4(a1 + (size_t)m * C + c);
-            const float4 dy = make_float4(a.x > 0.f ? d.x * sc : 0.f, a.y > 0.f ? d.y * sc : 0.f, a.z > 0.f ? d.z * sc : 0.f, a.w > 0.f ? d.w * sc : 0.f);
-            st4(da1 + (size_t)m * C + c, make_float4(rs.x * (dy.x - q1.x - y.x * q2.x), rs.y * (dy.y - q1.y - y.y * q2.y),
-                                                      rs.z * (dy.z - q1.z - y.z * q2.z), rs.w * (dy.w - q1.w - y.w * q2.w)));
+            GSAT_L1_OUT(m, h, d, a)
         }
+#undef GSAT_L1_OUT
     }
+#undef GSAT_L1_DY
 }
 
 // dh1[m,c] = rstd1 * (dy1 - S1 - yhat1*S2), written in place over da1 ; yhat1 recomputed from the pre-activation
