@@ -95,12 +95,13 @@ template <int LPR, bool HAS_EE, int NAGG>
 __global__ __launch_bounds__(PNA_BLOCK) void k_pna_fwd(
     const float* __restrict__ x, const float* __restrict__ att, const float* __restrict__ edge_emb,
     const int32_t* __restrict__ rowptr, const int32_t* __restrict__ col, const int32_t* __restrict__ eid,
-    int num_rows, int H, PnaCfg cfg, float* __restrict__ out, int rows_per_group) {
+    int num_rows, int H, PnaCfg cfg, float* __restrict__ out, int rows_per_group, int c0, int Hc) {
+    // channels [c0, c0 + Hc) of rows that are H wide: widths above 256 run as one launch per 256-channel chunk
     const LaneGroups<LPR, PNA_BLOCK> lg;
     constexpr int GPB = LaneGroups<LPR, PNA_BLOCK>::GPB;
     const int lane = lg.lane;
-    const int c = lane * 4;
-    const bool on = c < H;
+    const int c = c0 + lane * 4;
+    const bool on = lane * 4 < Hc;
     const int parts = HAS_EE ? 3 : 2;
     const int F = parts * H;
     const size_t out_stride = (size_t)cfg.S * cfg.A * F;
@@ -175,7 +176,8 @@ __global__ __launch_bounds__(PNA_BLOCK, HAS_EE ? 2 : 4) void k_pna_bwd_dst(
     const float* __restrict__ x, const float* __restrict__ att, const float* __restrict__ edge_emb,
     const float* __restrict__ dout, const int32_t* __restrict__ rowptr, const int32_t* __restrict__ col,
     const int32_t* __restrict__ eid, int num_rows, int H, PnaCfg cfg, float* __restrict__ dx_self,
-    float* __restrict__ dmsg, float* __restrict__ datt, float* __restrict__ dedge, int rows_per_group) {
+    float* __restrict__ dmsg, float* __restrict__ datt, float* __restrict__ dedge, int rows_per_group, int c0, int Hc) {
+    // channels [c0, c0 + Hc) of H-wide rows (see k_pna_fwd); chunks after the first ADD their share of datt (launches are stream-ordered)
     const LaneGroups<LPR, PNA_BLOCK> lg;
     constexpr int GPB = LaneGroups<LPR, PNA_BLOCK>::GPB;
     // The upstream gradient row (S*A*parts segments of H floats, 64 % of the kernel's bytes) is fetched by LDS-DMA at
@@ -183,8 +185,8 @@ __global__ __launch_bounds__(PNA_BLOCK, HAS_EE ? 2 : 4) void k_pna_bwd_dst(
     constexpr int MAXSEG = NAGG ? NAGG * (HAS_EE ? 3 : 2) : 8;
     __shared__ float4 stage[MAXSEG][PNA_BLOCK];
     const int lane = lg.lane;
-    const int c = lane * 4;
-    const bool on = c < H;
+    const int c = c0 + lane * 4;
+    const bool on = lane * 4 < Hc;
     const int parts = HAS_EE ? 3 : 2;
     const int F = parts * H;
     const size_t out_stride = (size_t)cfg.S * cfg.A * F;
@@ -383,7 +385,7 @@ __global__ __launch_bounds__(PNA_BLOCK, HAS_EE ? 2 : 4) void k_pna_bwd_dst(
                 }
                 if (datt) {
                     da = group_sum<LPR>(da);
-                    if (lane == 0) datt[e] = da;
+                    if (lane == 0) datt[e] = c0 ? datt[e] + da : da;
                 }
             }
         }
@@ -675,6 +677,9 @@ static inline int pna_lpr(int64_t H) {
     return q <= 4 ? 4 : q <= 8 ? 8 : q <= 16 ? 16 : q <= 20 ? 20 : q <= 32 ? 32 : 64;
 }
 
+constexpr int PNA_CHUNK = 256;       // channels per launch of the row kernels (64 lanes x float4)
+static inline bool pna_width_ok(int64_t H) { return H > 0 && H % 4 == 0 && H <= 512; }
+
 static inline void pna_grid(int64_t N, int lpr, int* nb, int* rpg) {
     const int gpb = (PNA_BLOCK / 64) * (64 / lpr);
     int64_t b = ceil_div(N, gpb);
@@ -738,13 +743,15 @@ int gsat_pna_fwd(const float* x, const float* att, const float* edge_emb, const 
     int rc = make_cfg(aggregators, A, scalers, S, avg_deg_lin, avg_deg_log, &cfg);
     if (rc) return rc;
     if (N == 0) return GSAT_OK;
-    const int lpr = pna_lpr(H);
-    GSAT_REQUIRE(lpr, GSAT_ERR_UNSUPPORTED, "gsat_pna_fwd: H=%lld must be a multiple of 4 and <= 256", (long long)H);
+    GSAT_REQUIRE(pna_width_ok(H), GSAT_ERR_UNSUPPORTED, "gsat_pna_fwd: H=%lld must be a multiple of 4 and <= 512", (long long)H);
     GSAT_REQUIRE(x && rowptr && out, GSAT_ERR_ARG, "gsat_pna_fwd: null pointer");   /* col / eid may be NULL when E == 0 */
+    const int nagg = fixed_aggregators(cfg);
+    for (int c0 = 0; c0 < (int)H; c0 += PNA_CHUNK) {
+    const int Hc = std::min<int>(PNA_CHUNK, (int)H - c0);
+    const int lpr = pna_lpr(Hc);
     int nb, rpg;
     pna_grid(N, lpr, &nb, &rpg);
-    const int nagg = fixed_aggregators(cfg);
-#define GO(L, EE, NA) k_pna_fwd<L, EE, NA><<<nb, PNA_BLOCK, 0, stream>>>(x, att, edge_emb, rowptr, col, eid, (int)N, (int)H, cfg, out, rpg)
+#define GO(L, EE, NA) k_pna_fwd<L, EE, NA><<<nb, PNA_BLOCK, 0, stream>>>(x, att, edge_emb, rowptr, col, eid, (int)N, (int)H, cfg, out, rpg, c0, Hc)
 #define CALL(L)                                                                                                              \
     do {                                                                                                                     \
         if (edge_emb) { if (nagg == 4) GO(L, true, 4); else if (nagg == 5) GO(L, true, 5); else GO(L, true, 0); }            \
@@ -754,6 +761,7 @@ int gsat_pna_fwd(const float* x, const float* att, const float* edge_emb, const 
 #undef CALL
 #undef GO
     GSAT_LAUNCH_CHECK();
+    }
     return GSAT_OK;
 }
 
@@ -767,13 +775,15 @@ int gsat_pna_bwd(const float* x, const float* att, const float* edge_emb, const 
     int rc = make_cfg(aggregators, A, scalers, S, avg_deg_lin, avg_deg_log, &cfg);
     if (rc) return rc;
     if (N == 0) return GSAT_OK;
-    const int lpr = pna_lpr(H);
-    GSAT_REQUIRE(lpr, GSAT_ERR_UNSUPPORTED, "gsat_pna_bwd: H=%lld must be a multiple of 4 and <= 256", (long long)H);
+    GSAT_REQUIRE(pna_width_ok(H), GSAT_ERR_UNSUPPORTED, "gsat_pna_bwd: H=%lld must be a multiple of 4 and <= 512", (long long)H);
     GSAT_REQUIRE(x && dout && rowptr && dx_self, GSAT_ERR_ARG, "gsat_pna_bwd: null pointer");   /* col / eid / dmsg may be NULL when E == 0 */
+    const int nagg = fixed_aggregators(cfg);
+    for (int c0 = 0; c0 < (int)H; c0 += PNA_CHUNK) {
+    const int Hc = std::min<int>(PNA_CHUNK, (int)H - c0);
+    const int lpr = pna_lpr(Hc);
     int nb, rpg;
     pna_grid(N, lpr, &nb, &rpg);
-    const int nagg = fixed_aggregators(cfg);
-#define GO(L, EE, NA) k_pna_bwd_dst<L, EE, NA><<<nb, PNA_BLOCK, 0, stream>>>(x, att, edge_emb, dout, rowptr, col, eid, (int)N, (int)H, cfg, dx_self, dmsg, datt, dedge_emb, rpg)
+#define GO(L, EE, NA) k_pna_bwd_dst<L, EE, NA><<<nb, PNA_BLOCK, 0, stream>>>(x, att, edge_emb, dout, rowptr, col, eid, (int)N, (int)H, cfg, dx_self, dmsg, datt, dedge_emb, rpg, c0, Hc)
 #define CALL(L)                                                                                                              \
     do {                                                                                                                     \
         if (edge_emb) { if (nagg == 4) GO(L, true, 4); else if (nagg == 5) GO(L, true, 5); else GO(L, true, 0); }            \
@@ -783,6 +793,7 @@ int gsat_pna_bwd(const float* x, const float* att, const float* edge_emb, const 
 #undef CALL
 #undef GO
     GSAT_LAUNCH_CHECK();
+    }
     return GSAT_OK;
 }
 

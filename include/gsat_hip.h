@@ -172,7 +172,8 @@ int gsat_aggr_sum_bwd(const float* x, const float* att, const float* edge_emb, c
  * std = sqrt(relu(var) + 1e-5) (so sqrt(1e-5) for empty rows); deg_i = unweighted in-degree.
  * replaces: PNAConvSimple.message + aggregate up to `post_nn`
  *           (src/models/conv_layers.py:160-185, aggregators :193-226, scalers :229-259).
- * aggregators / scalers are HOST int32 arrays (1..8 entries).  H % 4 == 0, H <= 256.
+ * aggregators / scalers are HOST int32 arrays (1..8 entries).  H % 4 == 0, H <= 512 (widths above 256 run as one launch per
+ * 256-channel chunk; the tiled backward below covers 64 <= H <= 256).
  */
 int gsat_pna_fwd(const float* x, const float* att, const float* edge_emb, const int32_t* rowptr,
                  const int32_t* col, const int32_t* eid, int64_t num_rows, int64_t H,
