@@ -24,6 +24,7 @@ SIGNATURES = {
     "gsat_rev_workspace_bytes": (SZ, [I64]),
     "gsat_build_csr": (INT, [P, P, I64, I64, P, P, P, P, P, SZ, P]),
     "gsat_reverse_edge_perm": (INT, [P, I64, I64, P, P, P, SZ, P]),
+    "gsat_reverse_edge_perm_csr": (INT, [P, P, P, P, P, P, P, P, I64, I64, P, P, P]),
     "gsat_segment_ptr": (INT, [P, I64, I64, P, P, P]),
     "gsat_gather_i64": (INT, [P, I64, P, I64, P, P]),
     "gsat_row_chunks_workspace_bytes": (SZ, [I64]),

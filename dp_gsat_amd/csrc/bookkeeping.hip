@@ -83,6 +83,37 @@ __global__ void k_pair_reverse2(const uint64_t* __restrict__ sorted, const int32
     if (sorted[i] != (sorted[E + i] & ~(1ull << key_bits))) atomicAdd(&flags[1], 1);
 }
 
+// ---- reverse-edge permutation from the two CSRs (no sort) ---------------------------------------------------------------------
+// The k-th copy (by edge id) of (s,d) pairs with the k-th copy of (d,s) -- the pairing of the stable sort above.  Copies of (s,d) sit
+// in the out-row of s and in the in-row of d, both in edge-id order: count the earlier ones in the SHORTER row, then walk the shorter
+// of in-row(s) / out-row(d) to the k-th copy of (d,s).  Hub-leaf edges cost the leaf's degree; 3 launches instead of a 2E-key sort.
+__global__ void k_rev_from_csr(const int32_t* __restrict__ src32, const int32_t* __restrict__ dst32, const int32_t* __restrict__ rp_dst,
+                               const int32_t* __restrict__ src_by_dst, const int32_t* __restrict__ eid_by_dst,
+                               const int32_t* __restrict__ rp_src, const int32_t* __restrict__ dst_by_src,
+                               const int32_t* __restrict__ eid_by_src, int64_t E, int32_t* __restrict__ rev, int32_t* __restrict__ flags) {
+    const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= E) return;
+    const int s = src32[e], d = dst32[e];
+    const int os_b = rp_src[s], os_e = rp_src[s + 1], id_b = rp_dst[d], id_e = rp_dst[d + 1];
+    int k = 0;
+    if (os_e - os_b <= id_e - id_b) {
+        for (int p = os_b; p < os_e && eid_by_src[p] < e; ++p) k += dst_by_src[p] == d;
+    } else {
+        for (int p = id_b; p < id_e && eid_by_dst[p] < e; ++p) k += src_by_dst[p] == s;
+    }
+    const int is_b = rp_dst[s], is_e = rp_dst[s + 1], od_b = rp_src[d], od_e = rp_src[d + 1];
+    int found = -1;
+    if (is_e - is_b <= od_e - od_b) {
+        for (int p = is_b; p < is_e; ++p)
+            if (src_by_dst[p] == d && k-- == 0) { found = eid_by_dst[p]; break; }
+    } else {
+        for (int p = od_b; p < od_e; ++p)
+            if (dst_by_src[p] == s && k-- == 0) { found = eid_by_src[p]; break; }
+    }
+    if (found < 0) { atomicAdd(&flags[1], 1); found = (int)e; }        // no partner: not symmetric; rev stays in bounds
+    rev[e] = found;
+}
+
 __global__ void k_finish_flags(int32_t* flags) { flags[0] = flags[1] == 0 ? 1 : 0; }
 
 __global__ void k_check_sorted(const int64_t* __restrict__ ids, int64_t n, int64_t num_seg, int32_t* flags) {
@@ -468,6 +499,25 @@ int gsat_reverse_edge_perm(const int64_t* edge_index, int64_t E, int64_t N, int3
     GSAT_CHECK_HIP(rocprim::radix_sort_pairs(temp, tb, kin, kout, ids, pq, (size_t)(2 * E), 0, (unsigned)(key_bits + 1), stream));
     k_pair_reverse2<<<ceil_div(E, B), B, 0, stream>>>(kout, pq, E, key_bits, rev, flags);
     GSAT_LAUNCH_CHECK();
+    k_finish_flags<<<1, 1, 0, stream>>>(flags);
+    GSAT_LAUNCH_CHECK();
+    return GSAT_OK;
+}
+
+int gsat_reverse_edge_perm_csr(const int32_t* src32, const int32_t* dst32, const int32_t* rowptr_dst, const int32_t* src_by_dst,
+                               const int32_t* eid_by_dst, const int32_t* rowptr_src, const int32_t* dst_by_src, const int32_t* eid_by_src,
+                               int64_t E, int64_t N, int32_t* rev, int32_t* flags, void* stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    GSAT_REQUIRE(E >= 0 && N >= 0 && flags, GSAT_ERR_ARG, "gsat_reverse_edge_perm_csr: bad argument");
+    GSAT_REQUIRE(E < (1ll << 31), GSAT_ERR_UNSUPPORTED, "gsat_reverse_edge_perm_csr: >2^31 edges");
+    GSAT_CHECK_HIP(gsat::zero_async(flags, 2 * sizeof(int32_t), stream));
+    if (E > 0) {
+        GSAT_REQUIRE(src32 && dst32 && rowptr_dst && src_by_dst && eid_by_dst && rowptr_src && dst_by_src && eid_by_src && rev && N > 0,
+                     GSAT_ERR_ARG, "gsat_reverse_edge_perm_csr: null pointer");
+        k_rev_from_csr<<<ceil_div(E, 256), 256, 0, stream>>>(src32, dst32, rowptr_dst, src_by_dst, eid_by_dst, rowptr_src, dst_by_src, eid_by_src,
+                                                             E, rev, flags);
+        GSAT_LAUNCH_CHECK();
+    }
     k_finish_flags<<<1, 1, 0, stream>>>(flags);
     GSAT_LAUNCH_CHECK();
     return GSAT_OK;

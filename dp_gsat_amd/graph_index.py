@@ -144,11 +144,16 @@ class BatchIndex:
     # -- reverse-edge permutation / undirected flag ----------------------------------------------
     def _build_rev(self):
         E, N, dev = self.E, self.N, self.device
-        ws_bytes = max(call_size("gsat_rev_workspace_bytes", E), 256)
-        ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
         rev = _i32(E, dev)
         flags = self._err[4:6]                   # zeroed by the call; lives next to the other status words
-        call("gsat_reverse_edge_perm", ptr(self.edge_index), E, N, ptr(rev), ptr(flags), ptr(ws), ws_bytes, stream())
+        if 2 * E <= (1 << 20) and os.environ.get("GSAT_REV_CSR", "1") != "0" and os.environ.get("GSAT_CSR_PAIR", "1") != "0":
+            # molecule-to-motif sized batches: pair the copies of (s,d) and (d,s) through the CSRs already built (3 launches, no sort)
+            call("gsat_reverse_edge_perm_csr", ptr(self.src32), ptr(self.dst32), ptr(self.rowptr_dst), ptr(self.src_by_dst), ptr(self.eid_by_dst),
+                 ptr(self.rowptr_src), ptr(self.dst_by_src), ptr(self.eid_by_src), E, N, ptr(rev), ptr(flags), stream())
+        else:
+            ws_bytes = max(call_size("gsat_rev_workspace_bytes", E), 256)
+            ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
+            call("gsat_reverse_edge_perm", ptr(self.edge_index), E, N, ptr(rev), ptr(flags), ptr(ws), ws_bytes, stream())
         self._rev_dev, self._rev_flags = rev, flags
         if _SYNC_FREE:
             return

@@ -88,6 +88,17 @@ int gsat_reverse_edge_perm(const int64_t* edge_index, int64_t num_edges, int64_t
                            void* stream);
 
 /*
+ * The same permutation and flags from the two CSRs of gsat_build_csr_pair (its clamped src32 / dst32 included), without a sort:
+ * the k-th copy (by edge id) of (s,d) pairs with the k-th copy of (d,s); an edge without a partner keeps rev[k] = k and counts
+ * in flags[1] (so flags[1] = number of unpaired edges here, 0 iff undirected -- the only property the callers use).
+ * Each edge walks the shorter of the two rows that hold its copies, so hub-leaf edges cost the leaf's degree.
+ */
+int gsat_reverse_edge_perm_csr(const int32_t* src32, const int32_t* dst32, const int32_t* rowptr_dst, const int32_t* src_by_dst,
+                               const int32_t* eid_by_dst, const int32_t* rowptr_src, const int32_t* dst_by_src,
+                               const int32_t* eid_by_src, int64_t num_edges, int64_t num_nodes, int32_t* rev, int32_t* flags,
+                               void* stream);
+
+/*
  * Segment pointer of a non-decreasing id vector (PyG `batch`): ptr[g]..ptr[g+1] = rows of
  * segment g.  flags[0] counts order violations / out-of-range ids (0 = valid input).
  * replaces: the per-call `degree(batch)` + scatter index of InstanceNorm and global pools

@@ -319,3 +319,26 @@ def test_undirected_line_graph_bit_exact(dev):
         G.line_graph_undirected(torch.tensor([[0, 1], [1, 2]], device=dev), 3)
     empty = G.line_graph_undirected(torch.zeros(2, 0, dtype=torch.int64, device=dev), 3)
     assert empty.edge_index.shape == (2, 0) and empty.num_dual_nodes == 0
+
+
+@pytest.mark.parametrize("seed", [0, 1, 2])
+def test_reverse_permutation_from_csr_with_duplicates_and_self_loops(dev, seed):
+    """Batches below 2^20 keys pair (s,d) copies with (d,s) copies through the CSRs (gsat_reverse_edge_perm_csr): k-th copy with k-th copy
+    by edge id -- the pairing of the oracle's stable sort -- including multi-edges, self loops and a hub; one missing partner clears the flag."""
+    from dp_gsat_amd.graph_index import BatchIndex
+    rng = np.random.default_rng(seed)
+    N = 60
+    a, b = rng.integers(0, N, 400), rng.integers(0, N, 400)
+    a, b = np.concatenate([a, a[:80], np.zeros(150, np.int64)]), np.concatenate([b, b[:80], rng.integers(1, N, 150)])     # repeats + hub 0
+    loops = rng.integers(0, N, 20)
+    src = np.concatenate([a, b, loops, loops[:5]])
+    dst = np.concatenate([b, a, loops, loops[:5]])
+    order = rng.permutation(src.size)
+    ei = torch.from_numpy(np.stack([src[order], dst[order]]))
+    assert obk.is_undirected(ei, N)
+    ix = BatchIndex(ei.to(dev), N)
+    rev = ix.rev
+    assert rev is not None and np.array_equal(rev.cpu().numpy().astype(np.int64), obk.reverse_edge_perm(ei, N))
+    cut = ei[:, 1:]                                        # one edge dropped: its partner has no partner any more (unless it was a loop)
+    if cut[0, :].ne(cut[1, :]).all() or not obk.is_undirected(cut, N):
+        assert BatchIndex(cut.contiguous().to(dev), N).rev is None
