@@ -240,10 +240,12 @@ __global__ void k_pair_gather(const int64_t* __restrict__ ei, const int32_t* __r
 //   count   cnt[key]++                                   (integer atomics: the totals do not depend on the order)
 //   scan    first[key] = exclusive sum of cnt            (rocPRIM, two launches)
 //   place   slot[first[key] + --cnt[key]] = edge id      (arbitrary order inside a row)
-//   order   every row's edge ids ascending               (= the stable order of the sort): rank sort by one thread for rows of <= 32
-//           entries, listed rows (longer) by a workgroup each: bitonic network in LDS per 4096-entry chunk, chunks merged by rank
-// The result is the unique (row, edge id) order, bit-identical to the sort's, in 7 launches.
-constexpr int COUNT_SHORT_ROW = 32;
+//   order   every row's edge ids ascending               (= the stable order of the sort): one thread per ENTRY counts the smaller ids
+//           of its row (rows of <= 1024 entries); longer rows are listed and ordered by a workgroup each: bitonic network in LDS per
+//           4096-entry chunk, chunks merged by rank
+// The result is the unique (row, edge id) order, bit-identical to the sort's, in 7 launches.  gsat_build_csr (one CSR; the edge-mode
+// extractor's edges-by-graph order) runs the same steps on its single key column.
+constexpr int COUNT_ELEM_ROW = 1024;
 constexpr int COUNT_CHUNK = 4096;
 constexpr int COUNT_LONG_BLOCK = 256;
 
@@ -261,44 +263,72 @@ __global__ void k_pair_count(const int64_t* __restrict__ ei, int64_t E, int64_t 
 }
 
 __global__ void k_pair_place(const int64_t* __restrict__ ei, int64_t E, int64_t N, const int64_t* __restrict__ first,
-                             int32_t* __restrict__ cnt, int32_t* __restrict__ slot) {
+                             int32_t* __restrict__ cnt, int32_t* __restrict__ slot, int32_t* __restrict__ rowkey) {
     int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (e >= E) return;
     int64_t s = ei[e], d = ei[E + e];
     s = (s < 0 || s >= N) ? N - 1 : s;
     d = (d < 0 || d >= N) ? N - 1 : d;
-    slot[(int32_t)first[d] + atomicSub(&cnt[d], 1) - 1] = (int32_t)e;
-    slot[(int32_t)first[N + s] + atomicSub(&cnt[N + s], 1) - 1] = (int32_t)e;
+    const int pd = (int32_t)first[d] + atomicSub(&cnt[d], 1) - 1, ps = (int32_t)first[N + s] + atomicSub(&cnt[N + s], 1) - 1;
+    slot[pd] = (int32_t)e; rowkey[pd] = (int32_t)d;
+    slot[ps] = (int32_t)e; rowkey[ps] = (int32_t)(N + s);
 }
 
-// one thread per key row (2N rows + the closing entry): row and hub-chunk pointers of both CSRs, short rows ordered, long rows listed
-__global__ void k_pair_order_short(const int64_t* __restrict__ first, int64_t E, int64_t N, const int32_t* __restrict__ slot,
-                                   int32_t* __restrict__ perm, int32_t* __restrict__ rowptr_dst, int32_t* __restrict__ rowptr_src,
-                                   int32_t* __restrict__ chunk_ptr_dst, int32_t* __restrict__ chunk_ptr_src, int32_t* __restrict__ status,
-                                   int32_t* __restrict__ long_rows, int32_t* __restrict__ long_count) {
-    int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (k > 2 * N) return;
-    const int64_t f = first[k];
-    const int beg = (int32_t)f, chunks = (int32_t)(f >> 32);
-    if (k <= N) { rowptr_dst[k] = beg; chunk_ptr_dst[k] = chunks; }
-    if (k == N) status[1] = chunks;                      // hub-chunk totals next to the range-error counter: one host read gets all
-    if (k >= N) {
-        const int c0 = (int32_t)(first[N] >> 32);
-        rowptr_src[k - N] = beg - (int32_t)E;
-        chunk_ptr_src[k - N] = chunks - c0;
-        if (k == 2 * N) status[2] = chunks - c0;
+// single key column (gsat_build_csr)
+__global__ void k_rows_count(const int64_t* __restrict__ rows, int64_t E, int64_t R, int32_t* __restrict__ cnt, int32_t* err) {
+    int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= E) return;
+    int64_t r = rows[e];
+    if (r < 0 || r >= R) { atomicAdd(err, 1); r = R - 1; }
+    atomicAdd(&cnt[r], 1);
+}
+
+__global__ void k_rows_place(const int64_t* __restrict__ rows, int64_t E, int64_t R, const int64_t* __restrict__ first,
+                             int32_t* __restrict__ cnt, int32_t* __restrict__ slot, int32_t* __restrict__ rowkey) {
+    int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= E) return;
+    int64_t r = rows[e];
+    r = (r < 0 || r >= R) ? R - 1 : r;
+    const int p = (int32_t)first[r] + atomicSub(&cnt[r], 1) - 1;
+    slot[p] = (int32_t)e; rowkey[p] = (int32_t)r;
+}
+
+// thread i <= R (R key rows + the closing entry): row pointers (PAIR: of both CSRs, with the hub-chunk pointers), long rows listed;
+// thread i < total: entry i takes its place in its row = the number of smaller edge ids in that row
+template <bool PAIR>
+__global__ void k_count_order(const int64_t* __restrict__ first, int64_t R, int64_t total, const int32_t* __restrict__ slot,
+                              const int32_t* __restrict__ rowkey, int32_t* __restrict__ perm, int64_t E, int64_t N,
+                              int32_t* __restrict__ rowptr_dst, int32_t* __restrict__ rowptr_src, int32_t* __restrict__ chunk_ptr_dst,
+                              int32_t* __restrict__ chunk_ptr_src, int32_t* __restrict__ status, int32_t* __restrict__ long_rows,
+                              int32_t* __restrict__ long_count) {
+    const int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (k <= R) {
+        const int64_t f = first[k];
+        const int beg = (int32_t)f;
+        if (PAIR) {
+            const int chunks = (int32_t)(f >> 32);
+            if (k <= N) { rowptr_dst[k] = beg; chunk_ptr_dst[k] = chunks; }
+            if (k == N) status[1] = chunks;              // hub-chunk totals next to the range-error counter: one host read gets all
+            if (k >= N) {
+                const int c0 = (int32_t)(first[N] >> 32);
+                rowptr_src[k - N] = beg - (int32_t)E;
+                chunk_ptr_src[k - N] = chunks - c0;
+                if (k == 2 * N) status[2] = chunks - c0;
+            }
+        } else {
+            rowptr_dst[k] = beg;
+        }
+        if (k < R && (int32_t)first[k + 1] - beg > COUNT_ELEM_ROW)
+            long_rows[atomicAdd(long_count, 1)] = (int32_t)k;    // order of the list is irrelevant: every listed row is ordered on its own
     }
-    if (k == 2 * N) return;
-    const int end = (int32_t)first[k + 1], deg = end - beg;
-    if (deg > COUNT_SHORT_ROW) {
-        long_rows[atomicAdd(long_count, 1)] = (int32_t)k;        // order of the list is irrelevant: every listed row is ordered on its own
-        return;
-    }
-    for (int i = beg; i < end; ++i) {
-        const int v = slot[i];
-        int r = 0;
-        for (int j = beg; j < end; ++j) r += slot[j] < v;
-        perm[beg + r] = v;
+    if (k < total) {
+        const int r = rowkey[k];
+        const int beg = (int32_t)first[r], end = (int32_t)first[r + 1];
+        if (end - beg > COUNT_ELEM_ROW) return;
+        const int v = slot[k];
+        int rank = 0;
+        for (int j = beg; j < end; ++j) rank += slot[j] < v;
+        perm[beg + rank] = v;
     }
 }
 
@@ -364,13 +394,14 @@ struct CountAndChunks {
     }
 };
 
-static size_t count_scan_temp_bytes(int64_t n) {
+static size_t count_scan_items_temp_bytes(int64_t items) {
     size_t tb = 0;
     auto in = rocprim::make_transform_iterator(rocprim::make_counting_iterator<int>(0), CountAndChunks{nullptr});
     int64_t* p = nullptr;
-    (void)rocprim::exclusive_scan(nullptr, tb, in, p, (int64_t)0, (size_t)(2 * n + 1), rocprim::plus<int64_t>(), (hipStream_t)0);
+    (void)rocprim::exclusive_scan(nullptr, tb, in, p, (int64_t)0, (size_t)std::max<int64_t>(items, 1), rocprim::plus<int64_t>(), (hipStream_t)0);
     return align_up(tb, 256) + 256;
 }
+static size_t count_scan_temp_bytes(int64_t n) { return count_scan_items_temp_bytes(2 * n + 1); }
 
 static bool counting_build(int64_t E) {
     static const int on = [] { const char* e = getenv("GSAT_CSR_COUNTING"); return e ? atoi(e) : 1; }();
@@ -426,9 +457,9 @@ extern "C" {
 int gsat_abi_version(void) { return GSAT_ABI_VERSION; }
 const char* gsat_last_error(void) { return gsat::get_error(); }
 
-size_t gsat_csr_workspace_bytes(int64_t E, int64_t /*num_rows*/) {
-    size_t e = (size_t)(E > 0 ? E : 1);
-    return 3 * align_up(e * 4, 256) + sort_temp_bytes<uint32_t>(E);
+size_t gsat_csr_workspace_bytes(int64_t E, int64_t num_rows) {
+    size_t e = (size_t)(E > 0 ? E : 1), r = (size_t)(num_rows > 0 ? num_rows + 2 : 2);
+    return 3 * align_up(e * 4, 256) + 3 * align_up(r * 4, 256) + std::max(sort_temp_bytes<uint32_t>(E), count_scan_items_temp_bytes(num_rows + 1));
 }
 
 size_t gsat_rev_workspace_bytes(int64_t E) {
@@ -451,17 +482,38 @@ int gsat_build_csr(const int64_t* rows, const int64_t* other, int64_t E, int64_t
     uint32_t* keys_in = ar.take<uint32_t>(E);
     uint32_t* keys_out = ar.take<uint32_t>(E);
     int32_t* ids = ar.take<int32_t>(E);
-    size_t tb = sort_temp_bytes<uint32_t>(E);
+    int32_t* cnt = ar.take<int32_t>(num_rows + 2);       // counting build: [0, R) row counts, [R] = 0 closes the scan, [R+1] = long rows listed
+    int64_t* first = ar.take<int64_t>(num_rows + 2);
+    size_t tb = std::max(sort_temp_bytes<uint32_t>(E), count_scan_items_temp_bytes(num_rows + 1));
     char* temp = ar.take<char>(tb);
     GSAT_REQUIRE(ar.ok() && temp, GSAT_ERR_WORKSPACE, "gsat_build_csr: workspace %zu < %zu", ws_bytes, ar.off);
 
     const int B = 256;
-    k_make_row_keys<<<ceil_div(E, B), B, 0, stream>>>(rows, E, num_rows, keys_in, ids, err_flag);
-    GSAT_LAUNCH_CHECK();
-    int end_bit = bits_for((uint64_t)(num_rows - 1));
-    GSAT_CHECK_HIP(rocprim::radix_sort_pairs(temp, tb, keys_in, keys_out, ids, perm, (size_t)E, 0, (unsigned)end_bit, stream));
-    k_lower_bounds<uint32_t><<<ceil_div(num_rows + 1, B), B, 0, stream>>>(keys_out, E, num_rows, rowptr);
-    GSAT_LAUNCH_CHECK();
+    if (counting_build(E / 2)) {                         // E keys <= 2^20: count / scan / place / order (see the pair build)
+        int32_t* slot = ids;
+        int32_t* rowkey = reinterpret_cast<int32_t*>(keys_out);
+        int32_t* long_rows = reinterpret_cast<int32_t*>(keys_in);
+        GSAT_CHECK_HIP(gsat::zero_async(cnt, (size_t)(num_rows + 2) * sizeof(int32_t), stream));
+        k_rows_count<<<ceil_div(E, B), B, 0, stream>>>(rows, E, num_rows, cnt, err_flag);
+        GSAT_LAUNCH_CHECK();
+        size_t ts = count_scan_items_temp_bytes(num_rows + 1);
+        auto cin = rocprim::make_transform_iterator(rocprim::make_counting_iterator<int>(0), CountAndChunks{cnt});
+        GSAT_CHECK_HIP(rocprim::exclusive_scan(temp, ts, cin, first, (int64_t)0, (size_t)(num_rows + 1), rocprim::plus<int64_t>(), stream));
+        k_rows_place<<<ceil_div(E, B), B, 0, stream>>>(rows, E, num_rows, first, cnt, slot, rowkey);
+        GSAT_LAUNCH_CHECK();
+        k_count_order<false><<<ceil_div(std::max<int64_t>(E, num_rows + 1), B), B, 0, stream>>>(
+            first, num_rows, E, slot, rowkey, perm, E, num_rows, rowptr, nullptr, nullptr, nullptr, nullptr, long_rows, cnt + num_rows + 1);
+        GSAT_LAUNCH_CHECK();
+        k_pair_order_long<<<256, COUNT_LONG_BLOCK, 0, stream>>>(first, slot, perm, long_rows, cnt + num_rows + 1);
+        GSAT_LAUNCH_CHECK();
+    } else {
+        k_make_row_keys<<<ceil_div(E, B), B, 0, stream>>>(rows, E, num_rows, keys_in, ids, err_flag);
+        GSAT_LAUNCH_CHECK();
+        int end_bit = bits_for((uint64_t)(num_rows - 1));
+        GSAT_CHECK_HIP(rocprim::radix_sort_pairs(temp, tb, keys_in, keys_out, ids, perm, (size_t)E, 0, (unsigned)end_bit, stream));
+        k_lower_bounds<uint32_t><<<ceil_div(num_rows + 1, B), B, 0, stream>>>(keys_out, E, num_rows, rowptr);
+        GSAT_LAUNCH_CHECK();
+    }
     if (other && other_sorted) {
         k_gather_narrow<<<ceil_div(E, B), B, 0, stream>>>(other, perm, E, other_sorted);
         GSAT_LAUNCH_CHECK();
@@ -562,17 +614,18 @@ int gsat_build_csr_pair(const int64_t* edge_index, int64_t E, int64_t N, int32_t
     const int B = 256;
     if (counting) {
         int32_t* slot = ids;                             // [2E] edge ids grouped by row, unordered inside a row
-        int32_t* long_rows = reinterpret_cast<int32_t*>(keys_in);      // [<= 2N rows longer than COUNT_SHORT_ROW <= 2E / 33 entries]
+        int32_t* long_rows = reinterpret_cast<int32_t*>(keys_in);      // [rows longer than COUNT_ELEM_ROW: fewer than 2E / 1024]
         GSAT_CHECK_HIP(gsat::zero_async(cnt, (size_t)(2 * N + 2) * sizeof(int32_t), stream));
         k_pair_count<<<ceil_div(E, B), B, 0, stream>>>(edge_index, E, N, cnt, src32, dst32, err_flag);
         GSAT_LAUNCH_CHECK();
         size_t ts = count_scan_temp_bytes(N);
         auto cin = rocprim::make_transform_iterator(rocprim::make_counting_iterator<int>(0), CountAndChunks{cnt});
         GSAT_CHECK_HIP(rocprim::exclusive_scan(temp, ts, cin, first, (int64_t)0, (size_t)(2 * N + 1), rocprim::plus<int64_t>(), stream));
-        k_pair_place<<<ceil_div(E, B), B, 0, stream>>>(edge_index, E, N, first, cnt, slot);
+        int32_t* rowkey = reinterpret_cast<int32_t*>(keys_out);
+        k_pair_place<<<ceil_div(E, B), B, 0, stream>>>(edge_index, E, N, first, cnt, slot, rowkey);
         GSAT_LAUNCH_CHECK();
-        k_pair_order_short<<<ceil_div(2 * N + 1, B), B, 0, stream>>>(first, E, N, slot, perm, rowptr_dst, rowptr_src, chunk_ptr_dst, chunk_ptr_src,
-                                                                       err_flag, long_rows, cnt + 2 * N + 1);
+        k_count_order<true><<<ceil_div(std::max<int64_t>(2 * E, 2 * N + 1), B), B, 0, stream>>>(
+            first, 2 * N, 2 * E, slot, rowkey, perm, E, N, rowptr_dst, rowptr_src, chunk_ptr_dst, chunk_ptr_src, err_flag, long_rows, cnt + 2 * N + 1);
         GSAT_LAUNCH_CHECK();
         k_pair_order_long<<<256, COUNT_LONG_BLOCK, 0, stream>>>(first, slot, perm, long_rows, cnt + 2 * N + 1);
         GSAT_LAUNCH_CHECK();
