@@ -34,6 +34,9 @@ SIGNATURES = {
     "gsat_aggr_sum_bwd": (INT, [P, P, P, P, P, P, P, I64, I64, I64, F32, P, P, P, P, P, P]),
     "gsat_pna_fwd": (INT, [P, P, P, P, P, P, I64, I64, P, INT, P, INT, F32, F32, P, P]),
     "gsat_pna_bwd": (INT, [P, P, P, P, P, P, P, I64, I64, P, INT, P, INT, F32, F32, P, P, P, P, P]),
+    "gsat_pna_long_row_floats": (SZ, [I64, I64, INT]),
+    "gsat_pna_fwd_long": (INT, [P, P, P, P, P, P, I64, I64, I64, P, INT, P, INT, F32, F32, P, P, P, P]),
+    "gsat_pna_bwd_long": (INT, [P, P, P, P, P, P, P, I64, I64, I64, P, INT, P, INT, F32, F32, P, P, P, P, P, P, P]),
     "gsat_pna_tile_plan": (INT, [I64, I64, P, P, P]),
     "gsat_pna_build_tiles": (INT, [P, P, P, P, P, I64, INT, INT, INT, P, P, P, P]),
     "gsat_pna_bwd_tiled": (INT, [P, P, P, P, P, P, P, I64, INT, INT, INT, P, P, I64, I64, I64, P, INT, P, INT, P, P, P, P, P, P]),

@@ -91,11 +91,215 @@ __device__ __forceinline__ Acc4 self_stats(float4 xi, float sa, float sa2, float
     return r;
 }
 
+// ---- long (hub) rows ----------------------------------------------------------------------------------------------------------
+// A row with more than GSAT_LONG_ROW_EDGES in-edges would keep ONE lane group busy for its whole length (a 1e5-edge hub: ~25 ms).
+// With the index's hub-chunk list (chunk_ptr, gsat_row_chunks) the row kernels treat it in three steps instead:
+//   k_pna_chunk_stats   one lane group per 256-edge chunk: running statistics of the chunk (sum, sum of squares, min, max and their
+//                       FIRST slots) per channel and the chunk's attention statistics -> record[item]
+//   k_pna_fwd / k_pna_bwd_dst   the row's lane group folds its chunks' records in chunk order (strict comparisons keep the first
+//                       occurrence across chunks, sums are added chunk by chunk: reproducible); the backward then stores the row's
+//                       routing coefficients in the record slot of its first chunk
+//   k_pna_chunk_apply   (backward) one lane group per chunk: the per-edge gradients of its 256 edges from that record
+// record = 6 planes of H per gathered part (x_j, edge_emb) + 8 scalars.
+constexpr int CH = GSAT_LONG_ROW_EDGES;
+
+__host__ __device__ __forceinline__ size_t pna_rec_floats(int H, int gparts) { return (size_t)6 * gparts * H + 8; }
+static inline int64_t pna_max_chunks(int64_t E) { return 2 * (E / CH) + 1; }
+
+__device__ __forceinline__ void pna_chunk_item(const int32_t* __restrict__ chunk_ptr, const int32_t* __restrict__ rowptr, int num_rows,
+                                               int item, int* row, int* beg, int* end) {
+    int lo = 0, hi = num_rows;                   // invariant: chunk_ptr[lo] <= item < chunk_ptr[hi]
+    while (hi - lo > 1) {
+        const int mid = (lo + hi) >> 1;
+        if (chunk_ptr[mid] <= item) lo = mid; else hi = mid;
+    }
+    *row = lo;
+    *beg = rowptr[lo] + (item - chunk_ptr[lo]) * CH;
+    *end = min(rowptr[lo + 1], *beg + CH);
+}
+
+__device__ __forceinline__ void st4i(float* p, int4 v) { *reinterpret_cast<int4*>(p) = v; }
+__device__ __forceinline__ int4 ld4i(const float* p) { return *reinterpret_cast<const int4*>(p); }
+
+// strict-comparison update of (min, max, first slots) by one message
+__device__ __forceinline__ void arg_update(const Acc4& a, float4 m, int kk, int4& jmin, int4& jmax) {
+    if (m.x < a.mn.x) jmin.x = kk; if (m.y < a.mn.y) jmin.y = kk; if (m.z < a.mn.z) jmin.z = kk; if (m.w < a.mn.w) jmin.w = kk;
+    if (m.x > a.mx.x) jmax.x = kk; if (m.y > a.mx.y) jmax.y = kk; if (m.z > a.mx.z) jmax.z = kk; if (m.w > a.mx.w) jmax.w = kk;
+}
+
+// fold a chunk's (statistics, first slots) into the row's: later chunks win only on strictly smaller / larger values
+__device__ __forceinline__ void rec_combine(Acc4& a, int4& jmin, int4& jmax, const float* __restrict__ r, int H, int c) {
+    const float4 s = ld4(r + c), q = ld4(r + H + c), mn = ld4(r + 2 * H + c), mx = ld4(r + 3 * H + c);
+    const int4 pmin = ld4i(r + 4 * H + c), pmax = ld4i(r + 5 * H + c);
+    a.s.x += s.x; a.s.y += s.y; a.s.z += s.z; a.s.w += s.w;
+    a.q.x += q.x; a.q.y += q.y; a.q.z += q.z; a.q.w += q.w;
+    if (mn.x < a.mn.x) { a.mn.x = mn.x; jmin.x = pmin.x; } if (mn.y < a.mn.y) { a.mn.y = mn.y; jmin.y = pmin.y; }
+    if (mn.z < a.mn.z) { a.mn.z = mn.z; jmin.z = pmin.z; } if (mn.w < a.mn.w) { a.mn.w = mn.w; jmin.w = pmin.w; }
+    if (mx.x > a.mx.x) { a.mx.x = mx.x; jmax.x = pmax.x; } if (mx.y > a.mx.y) { a.mx.y = mx.y; jmax.y = pmax.y; }
+    if (mx.z > a.mx.z) { a.mx.z = mx.z; jmax.z = pmax.z; } if (mx.w > a.mx.w) { a.mx.w = mx.w; jmax.w = pmax.w; }
+}
+
+template <int LPR, bool HAS_EE>
+__global__ __launch_bounds__(PNA_BLOCK) void k_pna_chunk_stats(
+    const float* __restrict__ x, const float* __restrict__ att, const float* __restrict__ edge_emb, const int32_t* __restrict__ rowptr,
+    const int32_t* __restrict__ col, const int32_t* __restrict__ eid, int num_rows, int H, const int32_t* __restrict__ chunk_ptr,
+    float* __restrict__ partial, int c0, int Hc) {
+    const LaneGroups<LPR, PNA_BLOCK> lg;
+    constexpr int GPB = LaneGroups<LPR, PNA_BLOCK>::GPB;
+    if (lg.grp < 0) return;
+    const int lane = lg.lane, c = c0 + lane * 4;
+    const bool on = lane * 4 < Hc;
+    constexpr int GP = HAS_EE ? 2 : 1;
+    const size_t rec = pna_rec_floats(H, GP);
+    const int total = chunk_ptr[num_rows];
+    for (int item = blockIdx.x * GPB + lg.grp; item < total; item += gridDim.x * GPB) {
+        int row, beg, end;
+        pna_chunk_item(chunk_ptr, rowptr, num_rows, item, &row, &beg, &end);
+        float sa = 0.f, sa2 = 0.f, amin = INFINITY, amax = -INFINITY, wfirst = 1.f;
+        int kmin_a = beg, kmax_a = beg;
+        Acc4 aj, ae;
+        aj.init(); ae.init();
+        int4 jmin = make_int4(beg, beg, beg, beg), jmax = jmin, emin = jmin, emax = jmin;
+        for (int k = beg; k < end; k += 4) {
+            const int nb = min(4, end - k);
+            int j[4], e[4];
+            float w[4];
+            float4 xv[4], ev[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) { j[u] = u < nb ? col[k + u] : 0; e[u] = u < nb ? eid[k + u] : 0; }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                w[u] = (u < nb && att) ? att[e[u]] : 1.f;
+                xv[u] = (u < nb && on) ? ld4(x + (size_t)j[u] * H + c) : f4zero();
+                if (HAS_EE) ev[u] = (u < nb && on) ? ld4(edge_emb + (size_t)e[u] * H + c) : f4zero();
+            }
+            if (k == beg) wfirst = w[0];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                if (u >= nb) continue;
+                const int kk = k + u;
+                sa += w[u]; sa2 = fmaf(w[u], w[u], sa2);
+                if (w[u] < amin) { amin = w[u]; kmin_a = kk; }
+                if (w[u] > amax) { amax = w[u]; kmax_a = kk; }
+                if (on) {
+                    const float4 m = f4scale(w[u], xv[u]);
+                    arg_update(aj, m, kk, jmin, jmax);
+                    aj.add(m);
+                    if (HAS_EE) {
+                        const float4 me = f4scale(w[u], ev[u]);
+                        arg_update(ae, me, kk, emin, emax);
+                        ae.add(me);
+                    }
+                }
+            }
+        }
+        float* r = partial + (size_t)item * rec;
+        if (on) {
+            st4(r + c, aj.s); st4(r + H + c, aj.q); st4(r + 2 * H + c, aj.mn); st4(r + 3 * H + c, aj.mx);
+            st4i(r + 4 * H + c, jmin); st4i(r + 5 * H + c, jmax);
+            if (HAS_EE) {
+                float* re = r + 6 * H;
+                st4(re + c, ae.s); st4(re + H + c, ae.q); st4(re + 2 * H + c, ae.mn); st4(re + 3 * H + c, ae.mx);
+                st4i(re + 4 * H + c, emin); st4i(re + 5 * H + c, emax);
+            }
+        }
+        if (lane == 0) {
+            float* sc = r + (size_t)6 * GP * H;
+            st4(sc, make_float4(sa, sa2, amin, amax));
+            st4(sc + 4, make_float4(__int_as_float(kmin_a), __int_as_float(kmax_a), wfirst, 0.f));
+        }
+    }
+}
+
+// backward of the long rows' edges from the row record written by k_pna_bwd_dst (same per-edge arithmetic as its pass 2)
+template <int LPR, bool HAS_EE>
+__global__ __launch_bounds__(PNA_BLOCK) void k_pna_chunk_apply(
+    const float* __restrict__ x, const float* __restrict__ att, const float* __restrict__ edge_emb, const int32_t* __restrict__ rowptr,
+    const int32_t* __restrict__ col, const int32_t* __restrict__ eid, int num_rows, int H, const int32_t* __restrict__ chunk_ptr,
+    const float* __restrict__ partial, float* __restrict__ dmsg, float* __restrict__ datt, float* __restrict__ dedge, int c0, int Hc) {
+    const LaneGroups<LPR, PNA_BLOCK> lg;
+    constexpr int GPB = LaneGroups<LPR, PNA_BLOCK>::GPB;
+    if (lg.grp < 0) return;
+    const int lane = lg.lane, c = c0 + lane * 4;
+    const bool on = lane * 4 < Hc;
+    constexpr int GP = HAS_EE ? 2 : 1;
+    const size_t rec = pna_rec_floats(H, GP);
+    const int total = chunk_ptr[num_rows];
+    for (int item = blockIdx.x * GPB + lg.grp; item < total; item += gridDim.x * GPB) {
+        int row, beg, end;
+        pna_chunk_item(chunk_ptr, rowptr, num_rows, item, &row, &beg, &end);
+        const float* r = partial + (size_t)chunk_ptr[row] * rec;
+        float4 Pj = f4zero(), Qj = f4zero(), gmn_j = f4zero(), gmx_j = f4zero(), Pe = f4zero(), Qe = f4zero(), gmn_e = f4zero(), gmx_e = f4zero();
+        int4 jmin = make_int4(-1, -1, -1, -1), jmax = jmin, emin = jmin, emax = jmin;
+        if (on) {
+            Pj = ld4(r + c); Qj = ld4(r + H + c); gmn_j = ld4(r + 2 * H + c); gmx_j = ld4(r + 3 * H + c);
+            jmin = ld4i(r + 4 * H + c); jmax = ld4i(r + 5 * H + c);
+            if (HAS_EE) {
+                const float* re = r + 6 * H;
+                Pe = ld4(re + c); Qe = ld4(re + H + c); gmn_e = ld4(re + 2 * H + c); gmx_e = ld4(re + 3 * H + c);
+                emin = ld4i(re + 4 * H + c); emax = ld4i(re + 5 * H + c);
+            }
+        }
+        const float4 ts = ld4(r + (size_t)6 * GP * H), ks = ld4(r + (size_t)6 * GP * H + 4);
+        const float t1 = ts.x, t2 = ts.y, tmn = ts.z, tmx = ts.w;
+        const int kmin_a = __float_as_int(ks.x), kmax_a = __float_as_int(ks.y);
+        for (int kb = beg; kb < end; kb += 4) {
+            const int nb = min(4, end - kb);
+            int j4[4], e4[4];
+            float w4[4];
+            float4 x4[4], ee4[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) { j4[u] = u < nb ? col[kb + u] : 0; e4[u] = u < nb ? eid[kb + u] : 0; }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                w4[u] = (u < nb && att) ? att[e4[u]] : 1.f;
+                x4[u] = (u < nb && on) ? ld4(x + (size_t)j4[u] * H + c) : f4zero();
+                if (HAS_EE) ee4[u] = (u < nb && on) ? ld4(edge_emb + (size_t)e4[u] * H + c) : f4zero();
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                if (u >= nb) continue;
+                const int k = kb + u, e = e4[u];
+                const float w = w4[u];
+                const float4 xj = x4[u];
+                float da = 0.f;
+                if (on) {
+                    float4 dm;
+                    dm.x = fmaf(Qj.x, w * xj.x, Pj.x) + (k == jmin.x ? gmn_j.x : 0.f) + (k == jmax.x ? gmx_j.x : 0.f);
+                    dm.y = fmaf(Qj.y, w * xj.y, Pj.y) + (k == jmin.y ? gmn_j.y : 0.f) + (k == jmax.y ? gmx_j.y : 0.f);
+                    dm.z = fmaf(Qj.z, w * xj.z, Pj.z) + (k == jmin.z ? gmn_j.z : 0.f) + (k == jmax.z ? gmx_j.z : 0.f);
+                    dm.w = fmaf(Qj.w, w * xj.w, Pj.w) + (k == jmin.w ? gmn_j.w : 0.f) + (k == jmax.w ? gmx_j.w : 0.f);
+                    st4(dmsg + (size_t)k * H + c, f4scale(w, dm));
+                    da += f4dot(dm, xj);
+                    if (HAS_EE) {
+                        const float4 ee = ee4[u];
+                        float4 de;
+                        de.x = fmaf(Qe.x, w * ee.x, Pe.x) + (k == emin.x ? gmn_e.x : 0.f) + (k == emax.x ? gmx_e.x : 0.f);
+                        de.y = fmaf(Qe.y, w * ee.y, Pe.y) + (k == emin.y ? gmn_e.y : 0.f) + (k == emax.y ? gmx_e.y : 0.f);
+                        de.z = fmaf(Qe.z, w * ee.z, Pe.z) + (k == emin.z ? gmn_e.z : 0.f) + (k == emax.z ? gmx_e.z : 0.f);
+                        de.w = fmaf(Qe.w, w * ee.w, Pe.w) + (k == emin.w ? gmn_e.w : 0.f) + (k == emax.w ? gmx_e.w : 0.f);
+                        if (dedge) st4(dedge + (size_t)e * H + c, f4scale(w, de));
+                        da += f4dot(de, ee);
+                    }
+                }
+                if (datt) {
+                    da = group_sum<LPR>(da);
+                    if (lane == 0) {
+                        da += t1 + w * t2 + (k == kmin_a ? tmn : 0.f) + (k == kmax_a ? tmx : 0.f);     // the x_i part, summed over the lanes by the row's group
+                        datt[e] = c0 ? datt[e] + da : da;
+                    }
+                }
+            }
+        }
+    }
+}
+
 template <int LPR, bool HAS_EE, int NAGG>
 __global__ __launch_bounds__(PNA_BLOCK) void k_pna_fwd(
     const float* __restrict__ x, const float* __restrict__ att, const float* __restrict__ edge_emb,
     const int32_t* __restrict__ rowptr, const int32_t* __restrict__ col, const int32_t* __restrict__ eid,
-    int num_rows, int H, PnaCfg cfg, float* __restrict__ out, int rows_per_group, int c0, int Hc) {
+    int num_rows, int H, PnaCfg cfg, float* __restrict__ out, int rows_per_group, int c0, int Hc,
+    const int32_t* __restrict__ chunk_ptr, const float* __restrict__ partial) {
     // channels [c0, c0 + Hc) of rows that are H wide: widths above 256 run as one launch per 256-channel chunk
     const LaneGroups<LPR, PNA_BLOCK> lg;
     constexpr int GPB = LaneGroups<LPR, PNA_BLOCK>::GPB;
@@ -116,7 +320,22 @@ __global__ __launch_bounds__(PNA_BLOCK) void k_pna_fwd(
         Acc4 aj, ae;
         aj.init(); ae.init();
         const float4 xi = on ? ld4(x + (size_t)row * H + c) : f4zero();
-        for (int k = beg; k < end; k += 4) {       // batches of 4 in-edges: all index / att / row loads issued together
+        const bool longrow = chunk_ptr != nullptr && end - beg > CH;
+        if (longrow) {              // hub row: fold the records k_pna_chunk_stats wrote for its chunks, in chunk order
+            constexpr int GP = HAS_EE ? 2 : 1;
+            const size_t rec = pna_rec_floats(H, GP);
+            int4 d0, d1;
+            for (int p = chunk_ptr[row]; p < chunk_ptr[row + 1]; ++p) {
+                const float* r = partial + (size_t)p * rec;
+                if (on) {
+                    rec_combine(aj, d0, d1, r, H, c);
+                    if (HAS_EE) rec_combine(ae, d0, d1, r + 6 * H, H, c);
+                }
+                const float4 sc = ld4(r + (size_t)6 * GP * H);
+                sa += sc.x; sa2 += sc.y; amin = fminf(amin, sc.z); amax = fmaxf(amax, sc.w);
+            }
+        }
+        for (int k = beg; k < (longrow ? beg : end); k += 4) {       // batches of 4 in-edges: all index / att / row loads issued together
             const int nb = min(4, end - k);
             int j[4], e[4];
             float w[4];
@@ -176,7 +395,8 @@ __global__ __launch_bounds__(PNA_BLOCK, HAS_EE ? 2 : 4) void k_pna_bwd_dst(
     const float* __restrict__ x, const float* __restrict__ att, const float* __restrict__ edge_emb,
     const float* __restrict__ dout, const int32_t* __restrict__ rowptr, const int32_t* __restrict__ col,
     const int32_t* __restrict__ eid, int num_rows, int H, PnaCfg cfg, float* __restrict__ dx_self,
-    float* __restrict__ dmsg, float* __restrict__ datt, float* __restrict__ dedge, int rows_per_group, int c0, int Hc) {
+    float* __restrict__ dmsg, float* __restrict__ datt, float* __restrict__ dedge, int rows_per_group, int c0, int Hc,
+    const int32_t* __restrict__ chunk_ptr, float* __restrict__ partial) {
     // channels [c0, c0 + Hc) of H-wide rows (see k_pna_fwd); chunks after the first ADD their share of datt (launches are stream-ordered)
     const LaneGroups<LPR, PNA_BLOCK> lg;
     constexpr int GPB = LaneGroups<LPR, PNA_BLOCK>::GPB;
@@ -220,7 +440,24 @@ __global__ __launch_bounds__(PNA_BLOCK, HAS_EE ? 2 : 4) void k_pna_bwd_dst(
         int lj[4] = {0, 0, 0, 0}, le[4] = {0, 0, 0, 0};      // indices / weights of the last batch: rows with <= 4 in-edges
         float lw[4] = {1.f, 1.f, 1.f, 1.f};                   // (all of a molecule graph) skip the second index + att round trip
         float wfirst = 1.f;                                   // att of the row's first slot (arg of att*x_i where x_i == 0)
-        for (int k = beg; k < end; k += 4) {
+        const bool longrow = chunk_ptr != nullptr && end - beg > CH;
+        constexpr int GP = HAS_EE ? 2 : 1;
+        const size_t rec = pna_rec_floats(H, GP);
+        if (longrow) {              // hub row: statistics and first slots from its chunks' records (k_pna_chunk_stats), in chunk order
+            for (int p = chunk_ptr[row]; p < chunk_ptr[row + 1]; ++p) {
+                const float* r = partial + (size_t)p * rec;
+                if (on) {
+                    rec_combine(aj, jmin, jmax, r, H, c);
+                    if (HAS_EE) rec_combine(ae, emin, emax, r + 6 * H, H, c);
+                }
+                const float4 sc = ld4(r + (size_t)6 * GP * H), ks = ld4(r + (size_t)6 * GP * H + 4);
+                sa += sc.x; sa2 += sc.y;
+                if (sc.z < amin) { amin = sc.z; kmin_a = __float_as_int(ks.x); }
+                if (sc.w > amax) { amax = sc.w; kmax_a = __float_as_int(ks.y); }
+                if (p == chunk_ptr[row]) wfirst = ks.z;
+            }
+        }
+        for (int k = beg; k < (longrow ? beg : end); k += 4) {
             const int nb = min(4, end - k);
             int j[4], e[4];
             float w[4];
@@ -332,6 +569,24 @@ __global__ __launch_bounds__(PNA_BLOCK, HAS_EE ? 2 : 4) void k_pna_bwd_dst(
             GSAT_FOLD(aj, 1, Pj, Qj, gmn_j, gmx_j)
             if (HAS_EE) { GSAT_FOLD(ae, 2, Pe, Qe, gmn_e, gmx_e) }
 #undef GSAT_FOLD
+        }
+        if (longrow) {              // the per-edge pass of a hub row runs chunk-parallel in k_pna_chunk_apply, from this record
+            float* r = partial + (size_t)chunk_ptr[row] * rec;          // the records of its chunks have been consumed above
+            if (on) {
+                st4(r + c, Pj); st4(r + H + c, Qj); st4(r + 2 * H + c, gmn_j); st4(r + 3 * H + c, gmx_j);
+                st4i(r + 4 * H + c, jmin); st4i(r + 5 * H + c, jmax);
+                if (HAS_EE) {
+                    float* re = r + 6 * H;
+                    st4(re + c, Pe); st4(re + H + c, Qe); st4(re + 2 * H + c, gmn_e); st4(re + 3 * H + c, gmx_e);
+                    st4i(re + 4 * H + c, emin); st4i(re + 5 * H + c, emax);
+                }
+            }
+            const float s1 = group_sum<LPR>(t1), s2 = group_sum<LPR>(t2), smn = group_sum<LPR>(tmn), smx = group_sum<LPR>(tmx);
+            if (lane == 0) {
+                st4(r + (size_t)6 * GP * H, make_float4(s1, s2, smn, smx));
+                st4(r + (size_t)6 * GP * H + 4, make_float4(__int_as_float(kmin_a), __int_as_float(kmax_a), 0.f, 0.f));
+            }
+            continue;
         }
         // ---- pass 2: per-edge gradients -------------------------------------------------------
         for (int kb = beg; kb < end; kb += 4) {
@@ -734,33 +989,102 @@ using namespace gsat;
 
 extern "C" {
 
-int gsat_pna_fwd(const float* x, const float* att, const float* edge_emb, const int32_t* rowptr, const int32_t* col,
-                 const int32_t* eid, int64_t N, int64_t H, const int32_t* aggregators, int A, const int32_t* scalers, int S,
-                 float avg_deg_lin, float avg_deg_log, float* out, void* stream_) {
-    hipStream_t stream = (hipStream_t)stream_;
-    GSAT_REQUIRE(N >= 0 && N < (1ll << 31), GSAT_ERR_ARG, "gsat_pna_fwd: bad N");
+static int pna_fwd_impl(const char* who, const float* x, const float* att, const float* edge_emb, const int32_t* rowptr, const int32_t* col,
+                        const int32_t* eid, int64_t N, int64_t E, int64_t H, const int32_t* aggregators, int A, const int32_t* scalers, int S,
+                        float avg_deg_lin, float avg_deg_log, float* out, const int32_t* chunk_ptr, float* partial, hipStream_t stream) {
+    GSAT_REQUIRE(N >= 0 && N < (1ll << 31), GSAT_ERR_ARG, "%s: bad N", who);
     PnaCfg cfg;
     int rc = make_cfg(aggregators, A, scalers, S, avg_deg_lin, avg_deg_log, &cfg);
     if (rc) return rc;
     if (N == 0) return GSAT_OK;
-    GSAT_REQUIRE(pna_width_ok(H), GSAT_ERR_UNSUPPORTED, "gsat_pna_fwd: H=%lld must be a multiple of 4 and <= 512", (long long)H);
-    GSAT_REQUIRE(x && rowptr && out, GSAT_ERR_ARG, "gsat_pna_fwd: null pointer");   /* col / eid may be NULL when E == 0 */
+    GSAT_REQUIRE(pna_width_ok(H), GSAT_ERR_UNSUPPORTED, "%s: H=%lld must be a multiple of 4 and <= 512", who, (long long)H);
+    GSAT_REQUIRE(x && rowptr && out, GSAT_ERR_ARG, "%s: null pointer", who);   /* col / eid may be NULL when E == 0 */
+    GSAT_REQUIRE(chunk_ptr == nullptr || partial != nullptr, GSAT_ERR_ARG, "%s: chunk_ptr needs the record workspace", who);
+    if (E <= CH) chunk_ptr = nullptr;                      // no row can be long
     const int nagg = fixed_aggregators(cfg);
     for (int c0 = 0; c0 < (int)H; c0 += PNA_CHUNK) {
-    const int Hc = std::min<int>(PNA_CHUNK, (int)H - c0);
-    const int lpr = pna_lpr(Hc);
-    int nb, rpg;
-    pna_grid(N, lpr, &nb, &rpg);
-#define GO(L, EE, NA) k_pna_fwd<L, EE, NA><<<nb, PNA_BLOCK, 0, stream>>>(x, att, edge_emb, rowptr, col, eid, (int)N, (int)H, cfg, out, rpg, c0, Hc)
+        const int Hc = std::min<int>(PNA_CHUNK, (int)H - c0);
+        const int lpr = pna_lpr(Hc);
+        int nb, rpg;
+        pna_grid(N, lpr, &nb, &rpg);
+        const int gpb = (PNA_BLOCK / 64) * (64 / lpr);
+        const int cb = chunk_ptr ? (int)std::min<int64_t>(ceil_div(pna_max_chunks(E), gpb), 256 * 16) : 0;
+#define GO(L, EE, NA) k_pna_fwd<L, EE, NA><<<nb, PNA_BLOCK, 0, stream>>>(x, att, edge_emb, rowptr, col, eid, (int)N, (int)H, cfg, out, rpg, c0, Hc, chunk_ptr, partial)
 #define CALL(L)                                                                                                              \
     do {                                                                                                                     \
-        if (edge_emb) { if (nagg == 4) GO(L, true, 4); else if (nagg == 5) GO(L, true, 5); else GO(L, true, 0); }            \
-        else { if (nagg == 4) GO(L, false, 4); else if (nagg == 5) GO(L, false, 5); else GO(L, false, 0); }                  \
+        if (edge_emb) {                                                                                                      \
+            if (cb) k_pna_chunk_stats<L, true><<<cb, PNA_BLOCK, 0, stream>>>(x, att, edge_emb, rowptr, col, eid, (int)N, (int)H, chunk_ptr, partial, c0, Hc); \
+            if (nagg == 4) GO(L, true, 4); else if (nagg == 5) GO(L, true, 5); else GO(L, true, 0);                          \
+        } else {                                                                                                             \
+            if (cb) k_pna_chunk_stats<L, false><<<cb, PNA_BLOCK, 0, stream>>>(x, att, edge_emb, rowptr, col, eid, (int)N, (int)H, chunk_ptr, partial, c0, Hc); \
+            if (nagg == 4) GO(L, false, 4); else if (nagg == 5) GO(L, false, 5); else GO(L, false, 0);                       \
+        }                                                                                                                    \
     } while (0)
-    GSAT_LPR_DISPATCH(lpr, CALL);
+        GSAT_LPR_DISPATCH(lpr, CALL);
 #undef CALL
 #undef GO
-    GSAT_LAUNCH_CHECK();
+        GSAT_LAUNCH_CHECK();
+    }
+    return GSAT_OK;
+}
+
+int gsat_pna_fwd(const float* x, const float* att, const float* edge_emb, const int32_t* rowptr, const int32_t* col,
+                 const int32_t* eid, int64_t N, int64_t H, const int32_t* aggregators, int A, const int32_t* scalers, int S,
+                 float avg_deg_lin, float avg_deg_log, float* out, void* stream_) {
+    return pna_fwd_impl("gsat_pna_fwd", x, att, edge_emb, rowptr, col, eid, N, 0, H, aggregators, A, scalers, S, avg_deg_lin, avg_deg_log, out,
+                        nullptr, nullptr, (hipStream_t)stream_);
+}
+
+size_t gsat_pna_long_row_floats(int64_t num_edges, int64_t H, int has_edge_emb) {
+    return (size_t)pna_max_chunks(num_edges > 0 ? num_edges : 0) * pna_rec_floats((int)H, has_edge_emb ? 2 : 1);
+}
+
+int gsat_pna_fwd_long(const float* x, const float* att, const float* edge_emb, const int32_t* rowptr, const int32_t* col,
+                      const int32_t* eid, int64_t N, int64_t E, int64_t H, const int32_t* aggregators, int A, const int32_t* scalers, int S,
+                      float avg_deg_lin, float avg_deg_log, float* out, const int32_t* chunk_ptr, float* partial, void* stream_) {
+    GSAT_REQUIRE(E >= 0 && E < (1ll << 31), GSAT_ERR_ARG, "gsat_pna_fwd_long: bad E");
+    return pna_fwd_impl("gsat_pna_fwd_long", x, att, edge_emb, rowptr, col, eid, N, E, H, aggregators, A, scalers, S, avg_deg_lin, avg_deg_log,
+                        out, chunk_ptr, partial, (hipStream_t)stream_);
+}
+
+static int pna_bwd_impl(const char* who, const float* x, const float* att, const float* edge_emb, const float* dout, const int32_t* rowptr,
+                        const int32_t* col, const int32_t* eid, int64_t N, int64_t E, int64_t H, const int32_t* aggregators, int A,
+                        const int32_t* scalers, int S, float avg_deg_lin, float avg_deg_log, float* dx_self, float* dmsg, float* datt,
+                        float* dedge_emb, const int32_t* chunk_ptr, float* partial, hipStream_t stream) {
+    GSAT_REQUIRE(N >= 0 && N < (1ll << 31), GSAT_ERR_ARG, "%s: bad N", who);
+    PnaCfg cfg;
+    int rc = make_cfg(aggregators, A, scalers, S, avg_deg_lin, avg_deg_log, &cfg);
+    if (rc) return rc;
+    if (N == 0) return GSAT_OK;
+    GSAT_REQUIRE(pna_width_ok(H), GSAT_ERR_UNSUPPORTED, "%s: H=%lld must be a multiple of 4 and <= 512", who, (long long)H);
+    GSAT_REQUIRE(x && dout && rowptr && dx_self, GSAT_ERR_ARG, "%s: null pointer", who);   /* col / eid / dmsg may be NULL when E == 0 */
+    GSAT_REQUIRE(chunk_ptr == nullptr || partial != nullptr, GSAT_ERR_ARG, "%s: chunk_ptr needs the record workspace", who);
+    if (E <= CH) chunk_ptr = nullptr;                      // no row can be long
+    const int nagg = fixed_aggregators(cfg);
+    for (int c0 = 0; c0 < (int)H; c0 += PNA_CHUNK) {
+        const int Hc = std::min<int>(PNA_CHUNK, (int)H - c0);
+        const int lpr = pna_lpr(Hc);
+        int nb, rpg;
+        pna_grid(N, lpr, &nb, &rpg);
+        const int gpb = (PNA_BLOCK / 64) * (64 / lpr);
+        const int cb = chunk_ptr ? (int)std::min<int64_t>(ceil_div(pna_max_chunks(E), gpb), 256 * 16) : 0;
+#define GO(L, EE, NA) k_pna_bwd_dst<L, EE, NA><<<nb, PNA_BLOCK, 0, stream>>>(x, att, edge_emb, dout, rowptr, col, eid, (int)N, (int)H, cfg, dx_self, dmsg, datt, dedge_emb, rpg, c0, Hc, chunk_ptr, partial)
+#define CALL(L)                                                                                                              \
+    do {                                                                                                                     \
+        if (edge_emb) {                                                                                                      \
+            if (cb) k_pna_chunk_stats<L, true><<<cb, PNA_BLOCK, 0, stream>>>(x, att, edge_emb, rowptr, col, eid, (int)N, (int)H, chunk_ptr, partial, c0, Hc); \
+            if (nagg == 4) GO(L, true, 4); else if (nagg == 5) GO(L, true, 5); else GO(L, true, 0);                          \
+            if (cb) k_pna_chunk_apply<L, true><<<cb, PNA_BLOCK, 0, stream>>>(x, att, edge_emb, rowptr, col, eid, (int)N, (int)H, chunk_ptr, partial, dmsg, datt, dedge_emb, c0, Hc); \
+        } else {                                                                                                             \
+            if (cb) k_pna_chunk_stats<L, false><<<cb, PNA_BLOCK, 0, stream>>>(x, att, edge_emb, rowptr, col, eid, (int)N, (int)H, chunk_ptr, partial, c0, Hc); \
+            if (nagg == 4) GO(L, false, 4); else if (nagg == 5) GO(L, false, 5); else GO(L, false, 0);                       \
+            if (cb) k_pna_chunk_apply<L, false><<<cb, PNA_BLOCK, 0, stream>>>(x, att, edge_emb, rowptr, col, eid, (int)N, (int)H, chunk_ptr, partial, dmsg, datt, dedge_emb, c0, Hc); \
+        }                                                                                                                    \
+    } while (0)
+        GSAT_LPR_DISPATCH(lpr, CALL);
+#undef CALL
+#undef GO
+        GSAT_LAUNCH_CHECK();
     }
     return GSAT_OK;
 }
@@ -769,32 +1093,17 @@ int gsat_pna_bwd(const float* x, const float* att, const float* edge_emb, const 
                  const int32_t* col, const int32_t* eid, int64_t N, int64_t H, const int32_t* aggregators, int A,
                  const int32_t* scalers, int S, float avg_deg_lin, float avg_deg_log, float* dx_self, float* dmsg,
                  float* datt, float* dedge_emb, void* stream_) {
-    hipStream_t stream = (hipStream_t)stream_;
-    GSAT_REQUIRE(N >= 0 && N < (1ll << 31), GSAT_ERR_ARG, "gsat_pna_bwd: bad N");
-    PnaCfg cfg;
-    int rc = make_cfg(aggregators, A, scalers, S, avg_deg_lin, avg_deg_log, &cfg);
-    if (rc) return rc;
-    if (N == 0) return GSAT_OK;
-    GSAT_REQUIRE(pna_width_ok(H), GSAT_ERR_UNSUPPORTED, "gsat_pna_bwd: H=%lld must be a multiple of 4 and <= 512", (long long)H);
-    GSAT_REQUIRE(x && dout && rowptr && dx_self, GSAT_ERR_ARG, "gsat_pna_bwd: null pointer");   /* col / eid / dmsg may be NULL when E == 0 */
-    const int nagg = fixed_aggregators(cfg);
-    for (int c0 = 0; c0 < (int)H; c0 += PNA_CHUNK) {
-    const int Hc = std::min<int>(PNA_CHUNK, (int)H - c0);
-    const int lpr = pna_lpr(Hc);
-    int nb, rpg;
-    pna_grid(N, lpr, &nb, &rpg);
-#define GO(L, EE, NA) k_pna_bwd_dst<L, EE, NA><<<nb, PNA_BLOCK, 0, stream>>>(x, att, edge_emb, dout, rowptr, col, eid, (int)N, (int)H, cfg, dx_self, dmsg, datt, dedge_emb, rpg, c0, Hc)
-#define CALL(L)                                                                                                              \
-    do {                                                                                                                     \
-        if (edge_emb) { if (nagg == 4) GO(L, true, 4); else if (nagg == 5) GO(L, true, 5); else GO(L, true, 0); }            \
-        else { if (nagg == 4) GO(L, false, 4); else if (nagg == 5) GO(L, false, 5); else GO(L, false, 0); }                  \
-    } while (0)
-    GSAT_LPR_DISPATCH(lpr, CALL);
-#undef CALL
-#undef GO
-    GSAT_LAUNCH_CHECK();
-    }
-    return GSAT_OK;
+    return pna_bwd_impl("gsat_pna_bwd", x, att, edge_emb, dout, rowptr, col, eid, N, 0, H, aggregators, A, scalers, S, avg_deg_lin, avg_deg_log,
+                        dx_self, dmsg, datt, dedge_emb, nullptr, nullptr, (hipStream_t)stream_);
+}
+
+int gsat_pna_bwd_long(const float* x, const float* att, const float* edge_emb, const float* dout, const int32_t* rowptr,
+                      const int32_t* col, const int32_t* eid, int64_t N, int64_t E, int64_t H, const int32_t* aggregators, int A,
+                      const int32_t* scalers, int S, float avg_deg_lin, float avg_deg_log, float* dx_self, float* dmsg,
+                      float* datt, float* dedge_emb, const int32_t* chunk_ptr, float* partial, void* stream_) {
+    GSAT_REQUIRE(E >= 0 && E < (1ll << 31), GSAT_ERR_ARG, "gsat_pna_bwd_long: bad E");
+    return pna_bwd_impl("gsat_pna_bwd_long", x, att, edge_emb, dout, rowptr, col, eid, N, E, H, aggregators, A, scalers, S, avg_deg_lin,
+                        avg_deg_log, dx_self, dmsg, datt, dedge_emb, chunk_ptr, partial, (hipStream_t)stream_);
 }
 
 // ---- tiled backward (see k_pna_bwd_tile) ------------------------------------------------------------------------------

@@ -10,6 +10,14 @@ from .graph_index import get_index
 from .ops import segment_pool
 
 
+class _UpdateMLP(nn.Sequential):
+    """GIN's node update Linear -> BatchNorm1d -> ReLU -> Linear (src/models/gin.py:55-62) with the same four modules and state_dict
+    keys; the ReLU is applied inside the BatchNorm kernels (forward and backward), module 2 stays as the placeholder it is upstream."""
+
+    def forward(self, x):
+        return self[3](self[1](self[0](x), fused_relu=True))
+
+
 class GIN(nn.Module):
     def __init__(self, x_dim, edge_attr_dim, num_class, multi_label, model_config):
         super().__init__()
@@ -38,8 +46,8 @@ class GIN(nn.Module):
 
     @staticmethod
     def MLP(in_channels: int, out_channels: int):
-        return nn.Sequential(Linear(in_channels, out_channels), BatchNorm1d(out_channels),
-                             nn.ReLU(inplace=True), Linear(out_channels, out_channels))
+        return _UpdateMLP(Linear(in_channels, out_channels), BatchNorm1d(out_channels),
+                          nn.ReLU(inplace=True), Linear(out_channels, out_channels))
 
     def pool(self, x, batch, index):
         return segment_pool(x, index.graphs(batch), mean=False)          # global_add_pool

@@ -123,6 +123,16 @@ class BatchIndex:
             self._partials[H] = buf
         return buf
 
+    def pna_partial(self, H: int, has_edge_emb: bool) -> torch.Tensor:
+        """Record workspace of the PNA kernels' long-row path (upper bound from E, no host sync); reused across calls on the same stream."""
+        key = ("pna", H, bool(has_edge_emb))
+        buf = self._partials.get(key)
+        if buf is None:
+            n = max(call_size("gsat_pna_long_row_floats", self.E, H, 1 if has_edge_emb else 0), 4)
+            buf = torch.empty(n, dtype=torch.float32, device=self.device)
+            self._partials[key] = buf
+        return buf
+
     def _validate_once(self):
         """Sync-free mode never reads the status words inside the step.  The kernels are memory-safe on bad input (ids are
         clamped), but the caller still deserves the ValueError: validate each distinct batch ONCE, outside stream capture

@@ -132,8 +132,14 @@ class PnaAggregate(torch.autograd.Function):
         a_arr = (ctypes.c_int32 * A)(*aggr_codes)
         s_arr = (ctypes.c_int32 * S)(*scaler_codes)
         out = torch.empty(N, S * A * F, dtype=torch.float32, device=x.device)
-        call("gsat_pna_fwd", ptr(x), ptr(attf), ptr(edge_emb), ptr(index.rowptr_dst), ptr(index.src_by_dst),
-             ptr(index.eid_by_dst), N, H, a_arr, A, s_arr, S, float(avg_lin), float(avg_log), ptr(out), stream())
+        hubs = index.long_rows[0]          # by-destination hub-chunk list, None when no row has more than GSAT_LONG_ROW_EDGES in-edges
+        if hubs is not None:
+            call("gsat_pna_fwd_long", ptr(x), ptr(attf), ptr(edge_emb), ptr(index.rowptr_dst), ptr(index.src_by_dst), ptr(index.eid_by_dst),
+                 N, index.E, H, a_arr, A, s_arr, S, float(avg_lin), float(avg_log), ptr(out), ptr(hubs),
+                 ptr(index.pna_partial(H, edge_emb is not None)), stream())
+        else:
+            call("gsat_pna_fwd", ptr(x), ptr(attf), ptr(edge_emb), ptr(index.rowptr_dst), ptr(index.src_by_dst),
+                 ptr(index.eid_by_dst), N, H, a_arr, A, s_arr, S, float(avg_lin), float(avg_log), ptr(out), stream())
         ctx.save_for_backward(x, attf, edge_emb)
         ctx.index = index
         ctx.cfg = (tuple(aggr_codes), tuple(scaler_codes), float(avg_lin), float(avg_log))
@@ -157,7 +163,12 @@ class PnaAggregate(torch.autograd.Function):
         dmsg = torch.empty(max(index.E, 1), H, dtype=torch.float32, device=dev)[: index.E]
         datt = torch.empty(index.E, dtype=torch.float32, device=dev) if need_att else None
         tiles = None
-        if edge_emb is None and _FIXED_PNA.get((aggr_codes, scaler_codes)) and os.environ.get("GSAT_PNA_TILED", "1") != "0":
+        hubs = index.long_rows[0]
+        from .graph_index import sync_free
+        # the tiled kernel walks a hub row with one lane group (correct, slow): batches known to hold hubs take the chunked two-pass path;
+        # inside a captured step (no host knowledge of the degrees) the tiled kernel stays
+        if (edge_emb is None and _FIXED_PNA.get((aggr_codes, scaler_codes)) and os.environ.get("GSAT_PNA_TILED", "1") != "0"
+                and (hubs is None or sync_free())):
             tiles = index.pna_tiles(H) or None
         if tiles is not None:
             # one launch: per-edge gradient rows stay in LDS and are summed per source there (no [E,H] round trip through HBM)
@@ -169,9 +180,14 @@ class PnaAggregate(torch.autograd.Function):
             return dx, (datt.view(ctx.att_shape) if need_att else None), None, None, None, None, None, None
         dx_self = torch.empty_like(x)
         dee = torch.empty_like(edge_emb) if need_ee else None
-        call("gsat_pna_bwd", ptr(x), ptr(attf), ptr(edge_emb), ptr(dout), ptr(index.rowptr_dst), ptr(index.src_by_dst),
-             ptr(index.eid_by_dst), N, H, a_arr, A, s_arr, S, avg_lin, avg_log, ptr(dx_self), ptr(dmsg), ptr(datt),
-             ptr(dee), stream())
+        if hubs is not None:
+            call("gsat_pna_bwd_long", ptr(x), ptr(attf), ptr(edge_emb), ptr(dout), ptr(index.rowptr_dst), ptr(index.src_by_dst),
+                 ptr(index.eid_by_dst), N, index.E, H, a_arr, A, s_arr, S, avg_lin, avg_log, ptr(dx_self), ptr(dmsg), ptr(datt),
+                 ptr(dee), ptr(hubs), ptr(index.pna_partial(H, edge_emb is not None)), stream())
+        else:
+            call("gsat_pna_bwd", ptr(x), ptr(attf), ptr(edge_emb), ptr(dout), ptr(index.rowptr_dst), ptr(index.src_by_dst),
+                 ptr(index.eid_by_dst), N, H, a_arr, A, s_arr, S, avg_lin, avg_log, ptr(dx_self), ptr(dmsg), ptr(datt),
+                 ptr(dee), stream())
         # second pass: sum the per-edge gradient rows of every source node through the inverted index
         dx = torch.empty_like(x)
         call("gsat_aggr_sum_fwd", ptr(dmsg), ptr(dx_self), None, None, ptr(index.rowptr_src),

@@ -209,6 +209,25 @@ int gsat_pna_bwd(const float* x, const float* att, const float* edge_emb, const 
                  float* dedge_emb, void* stream);
 
 /*
+ * The same two passes for batches with long (hub) rows: chunk_ptr = the by-destination hub-chunk list of gsat_build_csr_pair /
+ * gsat_row_chunks (rows of more than GSAT_LONG_ROW_EDGES in-edges split into chunks of that many), workspace =
+ * gsat_pna_long_row_floats(E, H, edge_emb != NULL) floats.  A long row is no longer walked by one lane group: its chunks are
+ * reduced in parallel (statistics + first min/max slots per chunk), folded in chunk order by the row's group, and -- backward --
+ * its per-edge gradients are written chunk-parallel from the row's routing record.  Bitwise reproducible; short rows unchanged.
+ * chunk_ptr == NULL behaves exactly like gsat_pna_fwd / gsat_pna_bwd.
+ */
+size_t gsat_pna_long_row_floats(int64_t num_edges, int64_t H, int has_edge_emb);
+int gsat_pna_fwd_long(const float* x, const float* att, const float* edge_emb, const int32_t* rowptr,
+                      const int32_t* col, const int32_t* eid, int64_t num_rows, int64_t num_edges, int64_t H,
+                      const int32_t* aggregators, int num_aggregators, const int32_t* scalers, int num_scalers,
+                      float avg_deg_lin, float avg_deg_log, float* out, const int32_t* chunk_ptr, float* workspace, void* stream);
+int gsat_pna_bwd_long(const float* x, const float* att, const float* edge_emb, const float* dout,
+                      const int32_t* rowptr, const int32_t* col, const int32_t* eid, int64_t num_rows, int64_t num_edges, int64_t H,
+                      const int32_t* aggregators, int num_aggregators, const int32_t* scalers, int num_scalers,
+                      float avg_deg_lin, float avg_deg_log, float* dx_self, float* dmsg, float* datt,
+                      float* dedge_emb, const int32_t* chunk_ptr, float* workspace, void* stream);
+
+/*
  * Tiled backward for the reference's aggregator lists (mean,min,max,std[,sum]; identity scaler; no edge_attr third): one
  * launch writes dx directly.  A workgroup owns a window ("tile") of consecutive destination rows and their in-edges; the
  * per-edge gradient rows stay in LDS and are summed per source there, so dmsg [E,H] is only touched by edges whose source lies

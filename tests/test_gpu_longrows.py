@@ -163,3 +163,53 @@ def test_counting_csr_build_orders_long_rows(dev, hub_deg):
     inv = np.empty(src.size, np.int64)
     inv[ix.eid_by_dst.cpu().numpy()] = np.arange(src.size)
     assert np.array_equal(ix.slot_dst_of_srcslot.cpu().numpy(), inv[ix.eid_by_src.cpu().numpy()])
+
+
+@pytest.mark.parametrize("H", [16, 80, 128, 320])
+@pytest.mark.parametrize("with_edge_attr", [False, True])
+@pytest.mark.parametrize("aggr,scalers", [
+    (["mean", "min", "max", "std"], ["identity"]),
+    (["mean", "min", "max", "std", "sum"], ["identity"]),
+    (["sum", "var", "max", "min"], ["identity", "amplification", "attenuation"]),
+])
+def test_pna_hub_rows_chunked(dev, H, with_edge_attr, aggr, scalers):
+    """Rows of 900 and 280 in-edges (> GSAT_LONG_ROW_EDGES = 256) take the chunked path of the PNA kernels: per-chunk statistics and
+    first min/max slots, folded per row in chunk order, per-edge gradients written chunk-parallel (gsat_pna_fwd_long / _bwd_long).
+    Ties are frequent (ReLU zeros in x), so the first-occurrence rule across chunk boundaries is exercised."""
+    from dp_gsat_amd.graph_index import BatchIndex
+    from dp_gsat_amd.ops import pna_aggregate
+    from tests.test_gpu_pna import close_weighted, std_conditioning
+    ei, N = hub_graph(3 + H, n=1200, hub_deg=(900, 280), extra=800)
+    E = ei.shape[1]
+    g = torch.Generator().manual_seed(H)
+    x = torch.randn(N, H, generator=g)
+    x[::3] = x[::3].relu()
+    att = torch.rand(E, 1, generator=g)
+    ee = torch.randn(E, H, generator=g) if with_edge_attr else None
+    avg = oops.pna_avg_deg(torch.from_numpy(obk.deg_histogram(ei, N)))
+    go = torch.randn(N, len(scalers) * len(aggr) * (3 if with_edge_attr else 2) * H, generator=g)
+    ref = {}
+    for dt in (torch.float32, torch.float64):
+        xo, ao = x.to(dt).clone().requires_grad_(True), att.to(dt).clone().requires_grad_(True)
+        eo = ee.to(dt).clone().requires_grad_(True) if with_edge_attr else None
+        oo = oops.pna_aggregate(xo, ei, ao, aggr, scalers, avg, eo)
+        oo.backward(go.to(dt))
+        ref[dt] = (oo, xo.grad, ao.grad, eo.grad if with_edge_attr else None)
+    ix = BatchIndex(ei.to(dev), N)
+    assert ix.long_rows[0] is not None
+    xd, ad = x.to(dev).requires_grad_(True), att.to(dev).requires_grad_(True)
+    ed = ee.to(dev).requires_grad_(True) if with_edge_attr else None
+    od = pna_aggregate(xd, ix, ad, ed, aggr, scalers, avg)
+    od.backward(go.to(dev))
+    r32, r64 = ref[torch.float32], ref[torch.float64]
+    close(od, r32[0], ref64=r64[0], what="out")
+    w_dx, w_e = std_conditioning(x, ei, att, N)
+    close_weighted(xd.grad, r32[1], r64[1], w_dx, "dx")
+    close_weighted(ad.grad, r32[2], r64[2], w_e, "datt")
+    if with_edge_attr:
+        close(ed.grad, r32[3], 2e-4, ref64=r64[3], what="dedge")
+    # run-to-run determinism of the chunked path
+    xd2, ad2 = x.to(dev).requires_grad_(True), att.to(dev).requires_grad_(True)
+    od2 = pna_aggregate(xd2, ix, ad2, ed.detach() if with_edge_attr else None, aggr, scalers, avg)
+    od2.backward(go.to(dev))
+    assert torch.equal(od, od2) and torch.equal(xd.grad, xd2.grad) and torch.equal(ad.grad, ad2.grad)
