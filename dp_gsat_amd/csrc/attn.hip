@@ -19,7 +19,7 @@ constexpr float IN_EPS = 1e-5f;
 constexpr int SB = 256;          // threads per block in the segmented kernels: 16 row slots x 16 lanes
 constexpr int SB_LANES = 16;     // lanes per row slot, one float4 each -> 64 channels per block
 constexpr int SB_SLOTS = 16;
-constexpr int SB_RC = 4;         // rows per slot kept in registers across the passes of the segmented kernels
+constexpr int SB_RC = 2;         // rows per slot kept in registers across the passes of the segmented kernels
 
 // row-major C[M,N] = alpha(=1) * op(A) op(B) + beta(0|1) * C through the hand-written MFMA GEMM (gemm.hip).
 // ta: A is given as [K,M]; tb: B is given as [N,K] (nn.Linear weight layout).
@@ -153,7 +153,7 @@ __global__ __launch_bounds__(SB) void k_seg_stats(PreAct<EDGE> pre, const int32_
     const bool on = c < C;
     const int beg = seg_ptr[g], end = seg_ptr[g + 1];
     const float inv_n = 1.f / (float)max(end - beg, 1);
-    // the first SB_RC rows of every slot stay in registers across the passes (segments of <= 64 rows -- every molecule graph -- make ONE
+    // the first SB_RC rows of every slot stay in registers across the passes (segments of <= 32 rows -- most molecule graphs -- make ONE
     // trip to memory instead of three dependent ones); longer segments re-read their tail, L2-hot, as before.  Same summation order.
     float4 hc[SB_RC];
     int mc[SB_RC];
@@ -326,48 +326,21 @@ __global__ __launch_bounds__(SB) void k_head_bwd_stats(const float* __restrict__
     const float sc = (training && p > 0.f) ? 1.f / (1.f - p) : 1.f;
     PreAct<false> pre{h2, nullptr, b2, nullptr, nullptr, C};
     float4 a1 = f4zero(), a2 = f4zero(), a3 = f4zero();
-    // rows, keep factors and dz of the first SB_RC rows per slot stay in registers for the APPLY pass (see k_seg_stats)
-    float4 hc[SB_RC], kc[SB_RC];
-    float dc[SB_RC];
-    int mc[SB_RC];
-#pragma unroll
-    for (int i = 0; i < SB_RC; ++i) {
-        const int r = beg + slot + i * SB_SLOTS;
-        mc[i] = (r < end && on) ? (order ? order[r] : r) : -1;
-    }
-#pragma unroll
-    for (int i = 0; i < SB_RC; ++i) {
-        hc[i] = mc[i] >= 0 ? pre.load(mc[i], c) : f4zero();
-        dc[i] = mc[i] >= 0 ? dz[mc[i]] : 0.f;
-        kc[i] = mc[i] >= 0 ? keep4(mask, seed, 2, mc[i], c, C, p, training != 0) : f4zero();
-    }
-    const int rest = beg + slot + SB_RC * SB_SLOTS;
-    float4 mu = f4zero(), rs = f4zero(), w = f4zero();
-#define GSAT_HEAD_ROW(H4, K4, D)                                                                                                   \
-    const float4 y = make_float4(((H4).x - mu.x) * rs.x, ((H4).y - mu.y) * rs.y, ((H4).z - mu.z) * rs.z, ((H4).w - mu.w) * rs.w);    \
-    const float4 dy = make_float4(y.x > 0.f ? (D) * w.x * (K4).x * sc : 0.f, y.y > 0.f ? (D) * w.y * (K4).y * sc : 0.f,             \
-                                  y.z > 0.f ? (D) * w.z * (K4).z * sc : 0.f, y.w > 0.f ? (D) * w.w * (K4).w * sc : 0.f);
     if (on) {
-        mu = ld4(mean + (size_t)g * C + c); rs = ld4(rstd + (size_t)g * C + c); w = ld4(w3 + c);
-#define GSAT_HEAD_ACC(H4, K4, D)                                                                                                   \
-        {                                                                                                                          \
-            GSAT_HEAD_ROW(H4, K4, D)                                                                                               \
-            a1.x += dy.x; a1.y += dy.y; a1.z += dy.z; a1.w += dy.w;                                                                \
-            a2.x = fmaf(dy.x, y.x, a2.x); a2.y = fmaf(dy.y, y.y, a2.y); a2.z = fmaf(dy.z, y.z, a2.z); a2.w = fmaf(dy.w, y.w, a2.w); \
-            a3.x = fmaf((D), fmaxf(y.x, 0.f) * (K4).x * sc, a3.x); a3.y = fmaf((D), fmaxf(y.y, 0.f) * (K4).y * sc, a3.y);          \
-            a3.z = fmaf((D), fmaxf(y.z, 0.f) * (K4).z * sc, a3.z); a3.w = fmaf((D), fmaxf(y.w, 0.f) * (K4).w * sc, a3.w);          \
-        }
-#pragma unroll
-        for (int i = 0; i < SB_RC; ++i)
-            if (mc[i] >= 0) GSAT_HEAD_ACC(hc[i], kc[i], dc[i])
-        for (int r = rest; r < end; r += SB_SLOTS) {
+        const float4 mu = ld4(mean + (size_t)g * C + c), rs = ld4(rstd + (size_t)g * C + c), w = ld4(w3 + c);
+        for (int r = beg + slot; r < end; r += SB_SLOTS) {
             const int m = order ? order[r] : r;
             const float d = dz[m];
-            const float4 h = pre.load(m, c);
-            const float4 k = keep4(mask, seed, 2, m, c, C, p, training != 0);
-            GSAT_HEAD_ACC(h, k, d)
+            float4 h = pre.load(m, c);
+            float4 k = keep4(mask, seed, 2, m, c, C, p, training != 0);
+            float4 y = make_float4((h.x - mu.x) * rs.x, (h.y - mu.y) * rs.y, (h.z - mu.z) * rs.z, (h.w - mu.w) * rs.w);
+            float4 dy = make_float4(y.x > 0.f ? d * w.x * k.x * sc : 0.f, y.y > 0.f ? d * w.y * k.y * sc : 0.f,
+                                    y.z > 0.f ? d * w.z * k.z * sc : 0.f, y.w > 0.f ? d * w.w * k.w * sc : 0.f);
+            a1.x += dy.x; a1.y += dy.y; a1.z += dy.z; a1.w += dy.w;
+            a2.x = fmaf(dy.x, y.x, a2.x); a2.y = fmaf(dy.y, y.y, a2.y); a2.z = fmaf(dy.z, y.z, a2.z); a2.w = fmaf(dy.w, y.w, a2.w);
+            a3.x = fmaf(d, fmaxf(y.x, 0.f) * k.x * sc, a3.x); a3.y = fmaf(d, fmaxf(y.y, 0.f) * k.y * sc, a3.y);
+            a3.z = fmaf(d, fmaxf(y.z, 0.f) * k.z * sc, a3.z); a3.w = fmaf(d, fmaxf(y.w, 0.f) * k.w * sc, a3.w);
         }
-#undef GSAT_HEAD_ACC
     }
     float4 t1 = slot_reduce(a1, sm, slot, lane);
     float4 t2 = slot_reduce(a2, sm, slot, lane);
@@ -384,25 +357,19 @@ __global__ __launch_bounds__(SB) void k_head_bwd_stats(const float* __restrict__
         __syncthreads();
         if (!on) return;
         const float4 s1 = bc1[lane], s2 = bc2[lane];
-#define GSAT_HEAD_OUT(M_, H4, K4, D)                                                                                               \
-        {                                                                                                                          \
-            GSAT_HEAD_ROW(H4, K4, D)                                                                                               \
-            st4(dh2 + (size_t)(M_) * C + c, make_float4(rs.x * (dy.x - s1.x - y.x * s2.x), rs.y * (dy.y - s1.y - y.y * s2.y),        \
-                                                         rs.z * (dy.z - s1.z - y.z * s2.z), rs.w * (dy.w - s1.w - y.w * s2.w)));     \
-        }
-#pragma unroll
-        for (int i = 0; i < SB_RC; ++i)
-            if (mc[i] >= 0) GSAT_HEAD_OUT(mc[i], hc[i], kc[i], dc[i])
-        for (int r = rest; r < end; r += SB_SLOTS) {
+        const float4 mu = ld4(mean + (size_t)g * C + c), rs = ld4(rstd + (size_t)g * C + c), w = ld4(w3 + c);
+        for (int r = beg + slot; r < end; r += SB_SLOTS) {
             const int m = order ? order[r] : r;
             const float d = dz[m];
             const float4 h = pre.load(m, c);
             const float4 k = keep4(mask, seed, 2, m, c, C, p, training != 0);
-            GSAT_HEAD_OUT(m, h, k, d)
+            const float4 y = make_float4((h.x - mu.x) * rs.x, (h.y - mu.y) * rs.y, (h.z - mu.z) * rs.z, (h.w - mu.w) * rs.w);
+            const float4 dy = make_float4(y.x > 0.f ? d * w.x * k.x * sc : 0.f, y.y > 0.f ? d * w.y * k.y * sc : 0.f,
+                                          y.z > 0.f ? d * w.z * k.z * sc : 0.f, y.w > 0.f ? d * w.w * k.w * sc : 0.f);
+            st4(dh2 + (size_t)m * C + c, make_float4(rs.x * (dy.x - s1.x - y.x * s2.x), rs.y * (dy.y - s1.y - y.y * s2.y),
+                                                      rs.z * (dy.z - s1.z - y.z * s2.z), rs.w * (dy.w - s1.w - y.w * s2.w)));
         }
-#undef GSAT_HEAD_OUT
     }
-#undef GSAT_HEAD_ROW
 }
 
 // dh2[m,c] = rstd2 * (dy2 - S1 - yhat2 * S2)

@@ -294,7 +294,10 @@ __global__ __launch_bounds__(PNA_BLOCK) void k_pna_chunk_apply(
     }
 }
 
-template <int LPR, bool HAS_EE, int NAGG>
+// LONG = false: every row of the lane group's span except, when a hub-chunk list is given, the rows of more than GSAT_LONG_ROW_EDGES
+// in-edges; LONG = true: exactly those rows (one lane group per row, found through the chunk list), their statistics folded from the
+// chunk records.  Two instantiations rather than a branch: the fold's registers would cost the common kernel a wave of occupancy.
+template <int LPR, bool HAS_EE, int NAGG, bool LONG>
 __global__ __launch_bounds__(PNA_BLOCK) void k_pna_fwd(
     const float* __restrict__ x, const float* __restrict__ att, const float* __restrict__ edge_emb,
     const int32_t* __restrict__ rowptr, const int32_t* __restrict__ col, const int32_t* __restrict__ eid,
@@ -311,17 +314,31 @@ __global__ __launch_bounds__(PNA_BLOCK) void k_pna_fwd(
     const size_t out_stride = (size_t)cfg.S * cfg.A * F;
     if (lg.grp < 0) return;
     const int grp = pna_xcd_remap(blockIdx.x, gridDim.x) * GPB + lg.grp;
-    int row = grp * rows_per_group;
-    const int row_end = min(num_rows, row + rows_per_group);
-    for (; row < row_end; ++row) {
+    int next_row = grp * rows_per_group;
+    const int row_end = min(num_rows, next_row + rows_per_group);
+    int item = blockIdx.x * GPB + lg.grp;
+    const int total = LONG ? chunk_ptr[num_rows] : 0;
+    for (;;) {
+        int row;
+        if (LONG) {                 // the lane group that draws a row's FIRST chunk owns the row
+            if (item >= total) break;
+            int b_, e_;
+            pna_chunk_item(chunk_ptr, rowptr, num_rows, item, &row, &b_, &e_);
+            const bool first = item == chunk_ptr[row];
+            item += gridDim.x * GPB;
+            if (!first) continue;
+        } else {
+            if (next_row >= row_end) break;
+            row = next_row++;
+        }
         const int beg = rowptr[row], end = rowptr[row + 1];
+        if (!LONG && chunk_ptr != nullptr && end - beg > CH) continue;
         const float cnt = (float)(end - beg);
         float sa = 0.f, sa2 = 0.f, amin = INFINITY, amax = -INFINITY;
         Acc4 aj, ae;
         aj.init(); ae.init();
         const float4 xi = on ? ld4(x + (size_t)row * H + c) : f4zero();
-        const bool longrow = chunk_ptr != nullptr && end - beg > CH;
-        if (longrow) {              // hub row: fold the records k_pna_chunk_stats wrote for its chunks, in chunk order
+        if (LONG) {                 // hub row: fold the records k_pna_chunk_stats wrote for its chunks, in chunk order
             constexpr int GP = HAS_EE ? 2 : 1;
             const size_t rec = pna_rec_floats(H, GP);
             int4 d0, d1;
@@ -335,7 +352,7 @@ __global__ __launch_bounds__(PNA_BLOCK) void k_pna_fwd(
                 sa += sc.x; sa2 += sc.y; amin = fminf(amin, sc.z); amax = fmaxf(amax, sc.w);
             }
         }
-        for (int k = beg; k < (longrow ? beg : end); k += 4) {       // batches of 4 in-edges: all index / att / row loads issued together
+        for (int k = beg; k < (LONG ? beg : end); k += 4) {       // batches of 4 in-edges: all index / att / row loads issued together
             const int nb = min(4, end - k);
             int j[4], e[4];
             float w[4];
@@ -390,7 +407,7 @@ __global__ __launch_bounds__(PNA_BLOCK) void k_pna_fwd(
 
 // NAGG = 4 | 5: the configurations of the reference's PNA YAMLs (aggregators mean,min,max,std[,sum]; scaler identity) with the
 // segment loop resolved at compile time; the generic instantiation covers every other aggregator / scaler list.
-template <int LPR, bool HAS_EE, int NAGG>
+template <int LPR, bool HAS_EE, int NAGG, bool LONG>
 __global__ __launch_bounds__(PNA_BLOCK, HAS_EE ? 2 : 4) void k_pna_bwd_dst(
     const float* __restrict__ x, const float* __restrict__ att, const float* __restrict__ edge_emb,
     const float* __restrict__ dout, const int32_t* __restrict__ rowptr, const int32_t* __restrict__ col,
@@ -415,10 +432,25 @@ __global__ __launch_bounds__(PNA_BLOCK, HAS_EE ? 2 : 4) void k_pna_bwd_dst(
     const int wave_base = (threadIdx.x >> 6) << 6;
     if (lg.grp < 0) return;
     const int grp = pna_xcd_remap(blockIdx.x, gridDim.x) * GPB + lg.grp;
-    int row = grp * rows_per_group;
-    const int row_end = min(num_rows, row + rows_per_group);
-    for (; row < row_end; ++row) {
+    int next_row = grp * rows_per_group;
+    const int row_end = min(num_rows, next_row + rows_per_group);
+    int item = blockIdx.x * GPB + lg.grp;
+    const int total = LONG ? chunk_ptr[num_rows] : 0;
+    for (;;) {
+        int row;
+        if (LONG) {                 // see k_pna_fwd
+            if (item >= total) break;
+            int b_, e_;
+            pna_chunk_item(chunk_ptr, rowptr, num_rows, item, &row, &b_, &e_);
+            const bool first = item == chunk_ptr[row];
+            item += gridDim.x * GPB;
+            if (!first) continue;
+        } else {
+            if (next_row >= row_end) break;
+            row = next_row++;
+        }
         const int beg = rowptr[row], end = rowptr[row + 1];
+        if (!LONG && chunk_ptr != nullptr && end - beg > CH) continue;
         const float cnt = (float)(end - beg);
         if (end == beg) {          // no in-edges: every aggregate is a constant of x
             if (on) st4(dx_self + (size_t)row * H + c, f4zero());
@@ -440,10 +472,9 @@ __global__ __launch_bounds__(PNA_BLOCK, HAS_EE ? 2 : 4) void k_pna_bwd_dst(
         int lj[4] = {0, 0, 0, 0}, le[4] = {0, 0, 0, 0};      // indices / weights of the last batch: rows with <= 4 in-edges
         float lw[4] = {1.f, 1.f, 1.f, 1.f};                   // (all of a molecule graph) skip the second index + att round trip
         float wfirst = 1.f;                                   // att of the row's first slot (arg of att*x_i where x_i == 0)
-        const bool longrow = chunk_ptr != nullptr && end - beg > CH;
         constexpr int GP = HAS_EE ? 2 : 1;
         const size_t rec = pna_rec_floats(H, GP);
-        if (longrow) {              // hub row: statistics and first slots from its chunks' records (k_pna_chunk_stats), in chunk order
+        if (LONG) {                 // hub row: statistics and first slots from its chunks' records (k_pna_chunk_stats), in chunk order
             for (int p = chunk_ptr[row]; p < chunk_ptr[row + 1]; ++p) {
                 const float* r = partial + (size_t)p * rec;
                 if (on) {
@@ -457,7 +488,7 @@ __global__ __launch_bounds__(PNA_BLOCK, HAS_EE ? 2 : 4) void k_pna_bwd_dst(
                 if (p == chunk_ptr[row]) wfirst = ks.z;
             }
         }
-        for (int k = beg; k < (longrow ? beg : end); k += 4) {
+        for (int k = beg; k < (LONG ? beg : end); k += 4) {
             const int nb = min(4, end - k);
             int j[4], e[4];
             float w[4];
@@ -570,7 +601,7 @@ __global__ __launch_bounds__(PNA_BLOCK, HAS_EE ? 2 : 4) void k_pna_bwd_dst(
             if (HAS_EE) { GSAT_FOLD(ae, 2, Pe, Qe, gmn_e, gmx_e) }
 #undef GSAT_FOLD
         }
-        if (longrow) {              // the per-edge pass of a hub row runs chunk-parallel in k_pna_chunk_apply, from this record
+        if (LONG) {                 // the per-edge pass of a hub row runs chunk-parallel in k_pna_chunk_apply, from this record
             float* r = partial + (size_t)chunk_ptr[row] * rec;          // the records of its chunks have been consumed above
             if (on) {
                 st4(r + c, Pj); st4(r + H + c, Qj); st4(r + 2 * H + c, gmn_j); st4(r + 3 * H + c, gmx_j);
@@ -1009,7 +1040,11 @@ static int pna_fwd_impl(const char* who, const float* x, const float* att, const
         pna_grid(N, lpr, &nb, &rpg);
         const int gpb = (PNA_BLOCK / 64) * (64 / lpr);
         const int cb = chunk_ptr ? (int)std::min<int64_t>(ceil_div(pna_max_chunks(E), gpb), 256 * 16) : 0;
-#define GO(L, EE, NA) k_pna_fwd<L, EE, NA><<<nb, PNA_BLOCK, 0, stream>>>(x, att, edge_emb, rowptr, col, eid, (int)N, (int)H, cfg, out, rpg, c0, Hc, chunk_ptr, partial)
+#define GO(L, EE, NA)                                                                                                                       \
+    do {                                                                                                                                    \
+        k_pna_fwd<L, EE, NA, false><<<nb, PNA_BLOCK, 0, stream>>>(x, att, edge_emb, rowptr, col, eid, (int)N, (int)H, cfg, out, rpg, c0, Hc, chunk_ptr, partial); \
+        if (cb) k_pna_fwd<L, EE, NA, true><<<cb, PNA_BLOCK, 0, stream>>>(x, att, edge_emb, rowptr, col, eid, (int)N, (int)H, cfg, out, rpg, c0, Hc, chunk_ptr, partial); \
+    } while (0)
 #define CALL(L)                                                                                                              \
     do {                                                                                                                     \
         if (edge_emb) {                                                                                                      \
@@ -1068,7 +1103,11 @@ static int pna_bwd_impl(const char* who, const float* x, const float* att, const
         pna_grid(N, lpr, &nb, &rpg);
         const int gpb = (PNA_BLOCK / 64) * (64 / lpr);
         const int cb = chunk_ptr ? (int)std::min<int64_t>(ceil_div(pna_max_chunks(E), gpb), 256 * 16) : 0;
-#define GO(L, EE, NA) k_pna_bwd_dst<L, EE, NA><<<nb, PNA_BLOCK, 0, stream>>>(x, att, edge_emb, dout, rowptr, col, eid, (int)N, (int)H, cfg, dx_self, dmsg, datt, dedge_emb, rpg, c0, Hc, chunk_ptr, partial)
+#define GO(L, EE, NA)                                                                                                                       \
+    do {                                                                                                                                    \
+        k_pna_bwd_dst<L, EE, NA, false><<<nb, PNA_BLOCK, 0, stream>>>(x, att, edge_emb, dout, rowptr, col, eid, (int)N, (int)H, cfg, dx_self, dmsg, datt, dedge_emb, rpg, c0, Hc, chunk_ptr, partial); \
+        if (cb) k_pna_bwd_dst<L, EE, NA, true><<<cb, PNA_BLOCK, 0, stream>>>(x, att, edge_emb, dout, rowptr, col, eid, (int)N, (int)H, cfg, dx_self, dmsg, datt, dedge_emb, rpg, c0, Hc, chunk_ptr, partial); \
+    } while (0)
 #define CALL(L)                                                                                                              \
     do {                                                                                                                     \
         if (edge_emb) {                                                                                                      \

@@ -24,6 +24,42 @@ _SYNC_FREE = False
 _VALIDATED: set = set()       # batches already validated in sync-free mode (BatchIndex._validate_once)
 
 
+# Hub rows without a host sync.  Whether a batch has rows above GSAT_LONG_ROW_EDGES is a device-side fact (status words [1], [2]).
+# The GIN ops read it back (one small sync per batch, as the reference's `is_undirected` does anyway); the PNA ops must not stall the
+# launch queue of a 1 ms step for it, so every new index queues an asynchronous copy of its status words into a pinned slot, later
+# indices harvest the copies that have landed, and `long_rows_nowait` answers from what is known: the exact flags once this batch's
+# copy (or a read-back) has arrived, otherwise "hubs possible" iff an earlier batch of the process had any.
+_HUBS_SEEN = [False]
+_STATUS_RING = []          # [pinned int32[8], event, owner weakref | None]
+
+
+def _harvest_status():
+    for slot in _STATUS_RING:
+        host, ev, owner = slot
+        if owner is not None and ev.query():
+            vals = host.tolist()
+            ix = owner()
+            if ix is not None and ix._long is None:
+                ix._long_async = (vals[1] > 0, vals[2] > 0)
+            if vals[1] > 0 or vals[2] > 0:
+                _HUBS_SEEN[0] = True
+            slot[2] = None
+
+
+def _queue_status(index):
+    import weakref
+    _harvest_status()
+    slot = next((s for s in _STATUS_RING if s[2] is None), None)
+    if slot is None:
+        if len(_STATUS_RING) >= 16:
+            return
+        slot = [torch.empty(8, dtype=torch.int32).pin_memory(), torch.cuda.Event(), None]
+        _STATUS_RING.append(slot)
+    slot[0].copy_(index._err, non_blocking=True)
+    slot[1].record()
+    slot[2] = weakref.ref(index)
+
+
 def set_sync_free(flag: bool) -> None:
     global _SYNC_FREE
     _SYNC_FREE = bool(flag)
@@ -83,6 +119,7 @@ class BatchIndex:
                 self._slot_dst_of_srcslot.copy_(inv[self.eid_by_src.long()])
             self._partials, self._long, self._tiles = {}, None, {}
             self._checked, self._rev, self._rev_dev, self._rev_flags, self._undirected, self._graphs = False, None, None, None, None, {}
+            self._long_async = None
             return
         ws_bytes = max(call_size("gsat_csr_pair_workspace_bytes", E, N), 256)
         ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
@@ -99,8 +136,11 @@ class BatchIndex:
         self._rev_flags = None
         self._undirected = None
         self._graphs = {}
+        self._long_async = None
         if _SYNC_FREE:
             self._validate_once()
+        elif not torch.cuda.is_current_stream_capturing():
+            _queue_status(self)
 
     @property
     def long_rows(self):
@@ -112,6 +152,22 @@ class BatchIndex:
         if self._long is None or not self._checked:
             self._readback()                     # also for tiny batches: one 32-byte copy answers every host-side question
         return (self.chunk_ptr_dst if self._long[0] else None, self.chunk_ptr_src if self._long[1] else None)
+
+    @property
+    def long_rows_nowait(self):
+        """`long_rows` without a host sync (see _HUBS_SEEN): exact when this batch's status is already on the host, else the chunk lists
+        (whose launches exit early on a batch without hubs) iff hubs have been seen before in this process, else (None, None)."""
+        if self._long is not None:
+            known = self._long
+        else:
+            if self._long_async is None and not _SYNC_FREE:
+                _harvest_status()
+            known = self._long_async
+        if known is not None:
+            return (self.chunk_ptr_dst if known[0] else None, self.chunk_ptr_src if known[1] else None)
+        if _SYNC_FREE or _HUBS_SEEN[0]:
+            return (self.chunk_ptr_dst, self.chunk_ptr_src)
+        return (None, None)
 
     def partial(self, H: int) -> torch.Tensor:
         """Scratch for the long-row partial sums of width H (upper bound, no host sync); reused across calls
@@ -176,6 +232,8 @@ class BatchIndex:
             self._err[1:3] = torch.cat([self.chunk_ptr_dst[-1:], self.chunk_ptr_src[-1:]])
         vals = self._err.tolist()              # every status word of this batch in one copy, no gather kernel
         self._long = (vals[1] > 0, vals[2] > 0)
+        if vals[1] > 0 or vals[2] > 0:
+            _HUBS_SEEN[0] = True
         self._checked = True
         if vals[0] != 0:
             raise ValueError("edge_index contains node ids outside [0, num_nodes)")

@@ -132,7 +132,7 @@ class PnaAggregate(torch.autograd.Function):
         a_arr = (ctypes.c_int32 * A)(*aggr_codes)
         s_arr = (ctypes.c_int32 * S)(*scaler_codes)
         out = torch.empty(N, S * A * F, dtype=torch.float32, device=x.device)
-        hubs = index.long_rows[0]          # by-destination hub-chunk list, None when no row has more than GSAT_LONG_ROW_EDGES in-edges
+        hubs = index.long_rows_nowait[0]   # by-destination hub-chunk list (no host sync), None when no row is known / expected to be long
         if hubs is not None:
             call("gsat_pna_fwd_long", ptr(x), ptr(attf), ptr(edge_emb), ptr(index.rowptr_dst), ptr(index.src_by_dst), ptr(index.eid_by_dst),
                  N, index.E, H, a_arr, A, s_arr, S, float(avg_lin), float(avg_log), ptr(out), ptr(hubs),
@@ -163,7 +163,7 @@ class PnaAggregate(torch.autograd.Function):
         dmsg = torch.empty(max(index.E, 1), H, dtype=torch.float32, device=dev)[: index.E]
         datt = torch.empty(index.E, dtype=torch.float32, device=dev) if need_att else None
         tiles = None
-        hubs = index.long_rows[0]
+        hubs = index.long_rows_nowait[0]
         from .graph_index import sync_free
         # the tiled kernel walks a hub row with one lane group (correct, slow): batches known to hold hubs take the chunked two-pass path;
         # inside a captured step (no host knowledge of the degrees) the tiled kernel stays
