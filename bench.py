@@ -435,10 +435,10 @@ def main():
     ap.add_argument("--no-full-step", action="store_true")
     ap.add_argument("--cpu-sample-graphs", type=int, default=0)
     ap.add_argument("--graph", dest="graph", action="store_true", default=None,
-                    help="capture the step into a hipGraph (torch.cuda.graph) and time replays; DEFAULT on one GPU for c1, c2, c4: the fork's "
+                    help="capture the step into a hipGraph (torch.cuda.graph) and time replays; DEFAULT on one GPU for c1-c4: the fork's "
                          "loaders are unshuffled (src/utils/get_data_loaders.py:133,141), so every batch recurs with the same shape each epoch "
                          "and a per-batch graph is what a training loop would replay; the index is still rebuilt inside every replay")
-    ap.add_argument("--eager", dest="graph", action="store_false", help="plain eager launches (the default for c3, the c5 workloads and --gpus > 1)")
+    ap.add_argument("--eager", dest="graph", action="store_false", help="plain eager launches (the default for the c5 workloads and --gpus > 1)")
     ap.add_argument("--sync-free", action="store_true", help="eager launches, but no device->host read inside the step (dp_gsat_amd.set_sync_free)")
     ap.add_argument("--roofline-only", action="store_true", help="only run the aggregation-kernel roofline leg (for rocprofv3 --pmc passes)")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only to rehearse N>1 on one GPU)")
@@ -452,9 +452,10 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     if args.graph is None:
-        # launch-bound batches (c1, c2, c4: 60-70 launches of a few microseconds) replay as one hipGraph; c3 / c5 are GPU-bound and
-        # measure the same or better eager (profiles/r02_bench_matrix.txt)
-        args.graph = world == 1 and "RANK" not in os.environ and args.workload in ("c1", "c2", "c4") and not args.sync_free
+        # launch-bound batches (c1, c2, c4: 60-70 launches of a few microseconds) replay as one hipGraph.  c3 issues ~110 launches in
+        # ~0.9 ms of host time against ~0.95 ms of GPU time: eager it measures the same on an idle host (0.965 ms) and 5-13 % worse on a
+        # loaded one (tools/host_time_c3.py, profiles/r02_summary.md), so it replays as a graph too; c5 is GPU-bound by a wide margin
+        args.graph = world == 1 and "RANK" not in os.environ and args.workload in ("c1", "c2", "c3", "c4") and not args.sync_free
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     # under torchrun (RANK set) the process group is initialised even at world size 1, so the RCCL path can be rehearsed on one GPU
     distributed = world > 1 or ("RANK" in os.environ and "MASTER_PORT" in os.environ)

@@ -24,6 +24,7 @@ _SYNC_FREE = False
 _VALIDATED: set = set()       # batches already validated in sync-free mode (BatchIndex._validate_once)
 
 
+
 # Hub rows without a host sync.  Whether a batch has rows above GSAT_LONG_ROW_EDGES is a device-side fact (status words [1], [2]).
 # The GIN ops read it back (one small sync per batch, as the reference's `is_undirected` does anyway); the PNA ops must not stall the
 # launch queue of a 1 ms step for it, so every new index queues an asynchronous copy of its status words into a pinned slot, later
@@ -34,6 +35,7 @@ _STATUS_RING = []          # [pinned int32[8], event, owner weakref | None]
 
 
 def _harvest_status():
+    bad = None
     for slot in _STATUS_RING:
         host, ev, owner = slot
         if owner is not None and ev.query():
@@ -44,10 +46,19 @@ def _harvest_status():
             if vals[1] > 0 or vals[2] > 0:
                 _HUBS_SEEN[0] = True
             slot[2] = None
+            if ix is None or not ix._checked:          # nobody read this batch's status back: report its errors now, late but not never
+                if vals[0] != 0:
+                    bad = "edge_index of an earlier batch contained node ids outside [0, num_nodes) (reported late: the PNA path never syncs)"
+                elif vals[3] != 0:
+                    bad = "`batch` of an earlier batch was not non-decreasing with ids in [0, num_graphs) (reported late: the PNA path never syncs)"
+    if bad:
+        raise ValueError(bad)
 
 
 def _queue_status(index):
     import weakref
+    if os.environ.get("GSAT_STATUS_ASYNC", "1") == "0":          # A/B switch: no status copies (hubs stay unknown on the PNA path)
+        return
     _harvest_status()
     slot = next((s for s in _STATUS_RING if s[2] is None), None)
     if slot is None:
@@ -58,6 +69,7 @@ def _queue_status(index):
     slot[0].copy_(index._err, non_blocking=True)
     slot[1].record()
     slot[2] = weakref.ref(index)
+    index._status_event = slot[1]
 
 
 def set_sync_free(flag: bool) -> None:
@@ -119,7 +131,7 @@ class BatchIndex:
                 self._slot_dst_of_srcslot.copy_(inv[self.eid_by_src.long()])
             self._partials, self._long, self._tiles = {}, None, {}
             self._checked, self._rev, self._rev_dev, self._rev_flags, self._undirected, self._graphs = False, None, None, None, None, {}
-            self._long_async = None
+            self._long_async, self._status_queued, self._status_event = None, False, None
             return
         ws_bytes = max(call_size("gsat_csr_pair_workspace_bytes", E, N), 256)
         ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
@@ -137,10 +149,9 @@ class BatchIndex:
         self._undirected = None
         self._graphs = {}
         self._long_async = None
+        self._status_queued, self._status_event = False, None
         if _SYNC_FREE:
             self._validate_once()
-        elif not torch.cuda.is_current_stream_capturing():
-            _queue_status(self)
 
     @property
     def long_rows(self):
@@ -148,7 +159,10 @@ class BatchIndex:
         entries -- then the aggregation calls skip the hub-chunk launch.  Costs one small read-back per index
         (per collated batch), merged with the undirected-flag read when that one is needed too."""
         if _SYNC_FREE and self._long is None:
-            return (self.chunk_ptr_dst, self.chunk_ptr_src)            # always run the (early-exit) hub-chunk launch
+            # inside a captured step nothing is read back: the (early-exit) hub-chunk launches are part of the step iff some batch of
+            # this process had a long row (every distinct batch is read back once by the warm-up runs, _validate_once).  Without them
+            # a hub row is still summed correctly, by one lane group.
+            return (self.chunk_ptr_dst, self.chunk_ptr_src) if _HUBS_SEEN[0] else (None, None)
         if self._long is None or not self._checked:
             self._readback()                     # also for tiny batches: one 32-byte copy answers every host-side question
         return (self.chunk_ptr_dst if self._long[0] else None, self.chunk_ptr_src if self._long[1] else None)
@@ -160,14 +174,16 @@ class BatchIndex:
         if self._long is not None:
             known = self._long
         else:
-            if self._long_async is None and not _SYNC_FREE:
-                _harvest_status()
+            if not _SYNC_FREE and not torch.cuda.is_current_stream_capturing():
+                if not self._status_queued:          # first use of this batch on the sync-free PNA path (its `batch` vector is registered by now)
+                    self._status_queued = True
+                    _queue_status(self)
+                elif self._long_async is None and self._status_event is not None and self._status_event.query():
+                    _harvest_status()          # one event query per call while this batch's copy is in flight, the ring only once it landed
             known = self._long_async
         if known is not None:
             return (self.chunk_ptr_dst if known[0] else None, self.chunk_ptr_src if known[1] else None)
-        if _SYNC_FREE or _HUBS_SEEN[0]:
-            return (self.chunk_ptr_dst, self.chunk_ptr_src)
-        return (None, None)
+        return (self.chunk_ptr_dst, self.chunk_ptr_src) if _HUBS_SEEN[0] else (None, None)
 
     def partial(self, H: int) -> torch.Tensor:
         """Scratch for the long-row partial sums of width H (upper bound, no host sync); reused across calls
@@ -387,3 +403,5 @@ def get_index(edge_index: torch.Tensor, num_nodes: int) -> BatchIndex:
 
 def clear_cache():
     _CACHE.clear()
+    for slot in _STATUS_RING:          # pending status copies of dropped batches are not reported any more
+        slot[2] = None

@@ -342,3 +342,38 @@ def test_reverse_permutation_from_csr_with_duplicates_and_self_loops(dev, seed):
     cut = ei[:, 1:]                                        # one edge dropped: its partner has no partner any more (unless it was a loop)
     if cut[0, :].ne(cut[1, :]).all() or not obk.is_undirected(cut, N):
         assert BatchIndex(cut.contiguous().to(dev), N).rev is None
+
+
+def test_pna_path_reports_bad_ids_late_and_learns_hubs_without_a_sync(dev):
+    """The PNA ops never read the status words back inside a step (a host sync costs the 1 ms C3 step ~10 %): every batch queues an
+    asynchronous copy instead, later batches harvest it.  Out-of-range ids therefore surface as ValueError one batch late, and the
+    chunked hub path switches on once a batch with a long row has been seen."""
+    import dp_gsat_amd as G
+    from dp_gsat_amd import graph_index as gi
+    from dp_gsat_amd.ops import pna_aggregate
+    G.clear_cache()
+    gi._HUBS_SEEN[0] = False
+    aggr, sc, avg = ["mean", "min", "max", "std"], ["identity"], {"lin": 1.0, "log": 1.0}
+    x = torch.randn(3, 16, device=dev)
+    bad = G.BatchIndex(torch.tensor([[0, 3, 1], [1, 0, 2]], device=dev), 3)          # id 3 == N
+    out = pna_aggregate(x, bad, None, None, aggr, sc, avg)                              # memory-safe (ids clamped), no error yet
+    assert torch.isfinite(out).all()
+    torch.cuda.synchronize()
+    good = G.BatchIndex(torch.tensor([[0, 1], [1, 0]], device=dev), 3)
+    with pytest.raises(ValueError, match="earlier batch"):
+        for _ in range(3):                                                             # first use queues its own copy, the next ones harvest
+            pna_aggregate(x, good, None, None, aggr, sc, avg)
+            torch.cuda.synchronize()
+    # hubs: unknown -> plain kernels (correct), after the status has landed -> chunk lists
+    hub = torch.stack([torch.arange(1, 400, device=dev), torch.zeros(399, dtype=torch.int64, device=dev)])
+    ix = G.BatchIndex(hub.contiguous(), 400)
+    assert ix.long_rows_nowait == (None, None)
+    torch.cuda.synchronize()
+    first = ix.long_rows_nowait
+    assert first[0] is not None and first[1] is None and gi._HUBS_SEEN[0]
+    ix2 = G.BatchIndex(hub.clone(), 400)
+    assert ix2.long_rows_nowait[0] is not None                                          # hubs seen before: chunk lists right away
+    xa = torch.randn(400, 16, device=dev)
+    assert torch.equal(pna_aggregate(xa, ix2, None, None, aggr, sc, avg), pna_aggregate(xa, ix, None, None, aggr, sc, avg))
+    gi._HUBS_SEEN[0] = False
+    G.clear_cache()
