@@ -17,8 +17,11 @@ namespace gsat {
 
 constexpr float IN_EPS = 1e-5f;
 constexpr int SB = 256;          // threads per block in the segmented kernels: 16 row slots x 16 lanes
-constexpr int SB_LANES = 16;     // lanes per row slot, one float4 each -> 64 channels per block
-constexpr int SB_SLOTS = 16;
+#ifndef GSAT_SB_LANES
+#define GSAT_SB_LANES 16
+#endif
+constexpr int SB_LANES = GSAT_SB_LANES;     // lanes per row slot, one float4 each -> 64 channels per block
+constexpr int SB_SLOTS = SB / SB_LANES;
 constexpr int SB_RC = 2;         // rows per slot kept in registers across the passes of the segmented kernels
 
 // row-major C[M,N] = alpha(=1) * op(A) op(B) + beta(0|1) * C through the hand-written MFMA GEMM (gemm.hip).
@@ -602,7 +605,7 @@ static inline int ew_blocks(int64_t work_items) {
 
 static int colsum(hipStream_t stream, const float* x, int64_t R, int C, float* out, float* scratch /* [256*C] */) {
     if (C <= 0) return GSAT_OK;
-    const int ctiles = (int)ceil_div(C, 64);
+    const int ctiles = (int)ceil_div(C, 4 * SB_LANES);
     if (R <= 0) { GSAT_CHECK_HIP(gsat::zero_async(out, sizeof(float) * C, stream)); return GSAT_OK; }
     int64_t RB = std::min<int64_t>(256, ceil_div(R, 64));
     if (RB <= 1) {
@@ -629,7 +632,7 @@ static int launch_seg_stats(hipStream_t stream, PreAct<EDGE> pre, const int32_t*
                             float* mean, float* rstd, float* part) {
     if (G <= 0) return GSAT_OK;
     const int C = pre.C;
-    const dim3 grid((unsigned)G, (unsigned)ceil_div(C, 64), (unsigned)Z);
+    const dim3 grid((unsigned)G, (unsigned)ceil_div(C, 4 * SB_LANES), (unsigned)Z);
     if (Z == 1) {
         k_seg_stats<EDGE, false><<<grid, SB, 0, stream>>>(pre, seg_ptr, order, mean, rstd);
     } else {
@@ -705,7 +708,7 @@ int gsat_attn_fwd(const gsat_attn_args* a, void* stream_) {
         GSAT_REQUIRE(a->fwd_workspace && a->fwd_workspace_bytes >= need, GSAT_ERR_WORKSPACE, "gsat_attn_fwd: workspace %zu < %zu", a->fwd_workspace_bytes, need);
         part = static_cast<float*>(a->fwd_workspace);
     }
-    const dim3 sgrid((unsigned)G, (unsigned)ceil_div(C1, 64), 1);
+    const dim3 sgrid((unsigned)G, (unsigned)ceil_div(C1, 4 * SB_LANES), 1);
     const SeedRef sref{a->seed, a->seed_dev};
     if (a->edge_mode) {
         PreAct<true> pre{a->P, a->Q, a->b1, a->src, a->dst, C1};
@@ -824,7 +827,7 @@ int gsat_attn_bwd(const gsat_attn_args* a, const gsat_attn_grads* gr, void* stre
     GSAT_LAUNCH_CHECK();
     if ((rc = colsum(stream, dz, M, 1, gr->db3, scratch))) return rc;
     // ---- through the head and the second InstanceNorm ------------------------------------------
-    const dim3 g2((unsigned)G, (unsigned)ceil_div(C2, 64), (unsigned)Z), g1((unsigned)G, (unsigned)ceil_div(C1, 64), (unsigned)Z);
+    const dim3 g2((unsigned)G, (unsigned)ceil_div(C2, 4 * SB_LANES), (unsigned)Z), g1((unsigned)G, (unsigned)ceil_div(C1, 4 * SB_LANES), (unsigned)Z);
     if (Z == 1)          // statistics and dh2 in one launch
         k_head_bwd_stats<true><<<g2, SB, 0, stream>>>(a->h2, a->b2, a->seg_ptr, a->seg_order, mean2, rstd2, a->mask2, SeedRef{a->seed, a->seed_dev}, a->p_drop,
                                                       a->training, a->W3, dz, C2, S1, S2, dw3p, dh2);
@@ -902,7 +905,7 @@ int gsat_instance_norm_fwd(const float* x, const int32_t* seg_ptr, const int32_t
     float* mean = stats;
     float* rstd = stats + (size_t)G * C;
     PreAct<false> pre{x, nullptr, nullptr, nullptr, nullptr, (int)C};
-    k_seg_stats<false, false><<<dim3((unsigned)G, (unsigned)ceil_div(C, 64), 1), SB, 0, stream>>>(pre, seg_ptr, seg_order, mean, rstd);
+    k_seg_stats<false, false><<<dim3((unsigned)G, (unsigned)ceil_div(C, 4 * SB_LANES), 1), SB, 0, stream>>>(pre, seg_ptr, seg_order, mean, rstd);
     k_norm_apply<false, false><<<ew_blocks(M * (C / 4)), 256, 0, stream>>>(pre, row_seg, mean, rstd, nullptr, SeedRef{0, nullptr}, 0, 0.f, 0, M, y);
     GSAT_LAUNCH_CHECK();
     return GSAT_OK;
@@ -916,7 +919,7 @@ int gsat_instance_norm_bwd(const float* y, const float* dy, const float* stats, 
     GSAT_REQUIRE(y && dy && stats && seg_ptr && row_seg && dx && workspace, GSAT_ERR_ARG, "gsat_instance_norm_bwd: null pointer");
     float* S1 = workspace;
     float* S2 = workspace + (size_t)G * C;
-    k_in_bwd_stats<<<dim3((unsigned)G, (unsigned)ceil_div(C, 64), 1), SB, 0, stream>>>(y, dy, seg_ptr, seg_order, (int)C, S1, S2);
+    k_in_bwd_stats<<<dim3((unsigned)G, (unsigned)ceil_div(C, 4 * SB_LANES), 1), SB, 0, stream>>>(y, dy, seg_ptr, seg_order, (int)C, S1, S2);
     k_in_bwd_apply<<<ew_blocks(M * (C / 4)), 256, 0, stream>>>(y, dy, row_seg, stats + (size_t)G * C, S1, S2, M, (int)C, dx);
     GSAT_LAUNCH_CHECK();
     return GSAT_OK;
