@@ -424,6 +424,9 @@ def cpu_baseline(wl, name, seed, sample_graphs=0, warmup=3, steps=10, budget_s=1
 
 
 def main():
+    if os.environ.get("GSAT_BENCH_WATCHDOG"):          # debugging aid: dump every thread's stack and exit if the run takes longer than this many seconds
+        import faulthandler
+        faulthandler.dump_traceback_later(float(os.environ["GSAT_BENCH_WATCHDOG"]), exit=True)
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=None, help="timed steps (default 200; 10 for the c5 workloads)")
@@ -537,6 +540,7 @@ def main():
     roof, cpu = None, None
     if rank == 0:
         hot.reuse_index = True
+        hot.flat = None          # rank 0 alone runs this leg: its in-step timing must not enter the gradient all-reduce (the other ranks wait at the barrier below)
         roof = aggregation_roofline(wl, data, dev, step_fn=hot.step)
         if not args.no_cpu_baseline and world == 1:          # reported at N=1 only
             cpu = cpu_baseline(wl, args.workload, args.seed, args.cpu_sample_graphs)

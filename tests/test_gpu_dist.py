@@ -106,3 +106,26 @@ def test_sharded_hip_step_matches_single_process(dev, backbone, edge_att):
     for p in procs:
         p.join(timeout=120)
     assert all(r[1] for r in res), res
+
+
+def test_bench_runs_with_two_ranks(dev):
+    """bench.py as the driver launches it for N > 1 (torch.distributed.run, one process per rank), here with two ranks sharing GPU 0 over
+    gloo: the run must END (round 2 found rank 0's roofline leg re-entering the gradient all-reduce while the other rank sat at the
+    closing barrier -- a hang at every N > 1) and print one JSON line for the whole job."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, GSAT_BENCH_WATCHDOG="200", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT"):
+        env.pop(k, None)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), os.path.join(root, "bench.py"), "--gpus", "2", "--workload", "c1", "--steps", "5", "--warmup", "2",
+           "--no-cpu-baseline", "--backend", "gloo"]
+    out = subprocess.run(cmd, cwd=root, env=env, capture_output=True, text=True, timeout=280)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, out.stdout[-2000:]
+    line = json.loads(lines[0])
+    assert line["n_gpus"] == 2 and line["scaling"] == "weak" and line["value"] > 0 and line["roofline"]["frac"] > 0
+    assert line["config"]["hipgraph"] is False and line["full_step"]["ms_per_step"] > 0
