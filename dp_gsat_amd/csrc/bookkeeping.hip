@@ -21,6 +21,18 @@ const char* get_error() { return g_err; }
 __global__ void k_zero_words(uint32_t* __restrict__ p, size_t n) {
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) p[i] = 0u;
 }
+__global__ void k_zero_words2(uint32_t* __restrict__ p, size_t n, uint32_t* __restrict__ q, size_t m) {
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n + m; i += (size_t)gridDim.x * blockDim.x) {
+        if (i < n) p[i] = 0u; else q[i - n] = 0u;
+    }
+}
+hipError_t zero2_async(void* p, size_t bytes_p, void* q, size_t bytes_q, hipStream_t stream) {       // two regions, one launch
+    const size_t n = bytes_p / 4, m = bytes_q / 4;
+    if (n + m == 0) return hipSuccess;
+    const unsigned blocks = (unsigned)std::min<size_t>((n + m + 255) / 256, 256 * 16);
+    k_zero_words2<<<blocks, 256, 0, stream>>>(static_cast<uint32_t*>(p), n, static_cast<uint32_t*>(q), m);
+    return hipGetLastError();
+}
 hipError_t zero_async(void* p, size_t bytes, hipStream_t stream) {
     const size_t n = bytes / 4;
     if (n == 0) return hipSuccess;
@@ -615,6 +627,7 @@ int gsat_build_csr_pair(const int64_t* edge_index, int64_t E, int64_t N, int32_t
                  "gsat_build_csr_pair: bad argument");
     GSAT_REQUIRE(2 * E < (1ll << 31) && 2 * N + 2 < (1ll << 31), GSAT_ERR_UNSUPPORTED, "gsat_build_csr_pair: >2^30 entries");
     if (E == 0) {
+        GSAT_CHECK_HIP(gsat::zero_async(err_flag, 4 * sizeof(int32_t), stream));
         GSAT_CHECK_HIP(gsat::zero_async(rowptr_dst, (size_t)(N + 1) * sizeof(int32_t), stream));
         GSAT_CHECK_HIP(gsat::zero_async(rowptr_src, (size_t)(N + 1) * sizeof(int32_t), stream));
         GSAT_CHECK_HIP(gsat::zero_async(chunk_ptr_dst, (size_t)(N + 1) * sizeof(int32_t), stream));
@@ -640,7 +653,7 @@ int gsat_build_csr_pair(const int64_t* edge_index, int64_t E, int64_t N, int32_t
     if (counting) {
         int32_t* slot = ids;                             // [2E] edge ids grouped by row, unordered inside a row
         int32_t* long_rows = reinterpret_cast<int32_t*>(keys_in);      // [rows longer than COUNT_ELEM_ROW: fewer than 2E / 1024]
-        GSAT_CHECK_HIP(gsat::zero_async(cnt, (size_t)(2 * N + 2) * sizeof(int32_t), stream));
+        GSAT_CHECK_HIP(zero2_async(cnt, (size_t)(2 * N + 2) * sizeof(int32_t), err_flag, 4 * sizeof(int32_t), stream));      // counts + the four status words
         k_pair_count<<<ceil_div(E, B), B, 0, stream>>>(edge_index, E, N, cnt, src32, dst32, err_flag);
         GSAT_LAUNCH_CHECK();
         size_t ts = count_scan_temp_bytes(N);
@@ -655,6 +668,7 @@ int gsat_build_csr_pair(const int64_t* edge_index, int64_t E, int64_t N, int32_t
         k_pair_order_long<<<256, COUNT_LONG_BLOCK, 0, stream>>>(first, slot, perm, long_rows, cnt + 2 * N + 1);
         GSAT_LAUNCH_CHECK();
     } else {
+        GSAT_CHECK_HIP(gsat::zero_async(err_flag, 4 * sizeof(int32_t), stream));
         k_make_pair_keys<<<ceil_div(E, B), B, 0, stream>>>(edge_index, E, N, keys_in, ids, src32, dst32, err_flag);
         GSAT_LAUNCH_CHECK();
         const int end_bit = bits_for((uint64_t)(2 * N - 1));

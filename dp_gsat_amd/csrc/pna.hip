@@ -696,8 +696,10 @@ constexpr int TILE_BLOCK = 512;
 
 // desc[t] = (first row of window t, rowptr_dst[row], rowptr_src[row], 0); desc[T] closes the last window
 __global__ void k_pna_tiles(const int32_t* __restrict__ node_ptr, const int32_t* __restrict__ node_seg, const int32_t* __restrict__ rowptr,
-                            const int32_t* __restrict__ rowptr_src, int N, int TN, int slack, int T, int4* __restrict__ desc) {
+                            const int32_t* __restrict__ rowptr_src, int N, int TN, int slack, int T, int4* __restrict__ desc,
+                            int32_t* __restrict__ spill_count) {
     const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t == 0 && spill_count) *spill_count = 0;          // the list is filled by the NEXT launch (k_pna_spill_rows): no separate zeroing launch
     if (t > T) return;
     const int64_t p = (int64_t)t * TN;
     int start = N;
@@ -1172,10 +1174,9 @@ int gsat_pna_build_tiles(const int32_t* node_ptr, const int32_t* node_seg, const
     GSAT_REQUIRE((node_ptr == nullptr) == (node_seg == nullptr), GSAT_ERR_ARG, "gsat_pna_build_tiles: node_ptr and node_seg go together");
     const int64_t T = ceil_div(N, rows_nominal);
     k_pna_tiles<<<(int)ceil_div(T + 1, 256), 256, 0, stream>>>(node_ptr, node_seg, rowptr, rowptr_src, (int)N, rows_nominal, node_seg ? rows_slack : 0, (int)T,
-                                                               (int4*)tile_desc);
+                                                               (int4*)tile_desc, spill_count);
     GSAT_LAUNCH_CHECK();
     GSAT_REQUIRE(spill_rows && spill_count && edges_cap > 0, GSAT_ERR_ARG, "gsat_pna_build_tiles: null spill list");
-    GSAT_CHECK_HIP(gsat::zero_async(spill_count, sizeof(int32_t), stream));
     if (N > 0 && slot_dst_of_srcslot) {
         k_pna_spill_rows<<<(int)ceil_div(N, 256), 256, 0, stream>>>((const int4*)tile_desc, rows_nominal, edges_cap, rowptr_src, slot_dst_of_srcslot,
                                                                    (int)N, spill_rows, spill_count);

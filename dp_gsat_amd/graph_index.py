@@ -100,7 +100,10 @@ class BatchIndex:
         dev = self.device
         E, N = self.E, self.N
         # status words, read back together: [0] range errors, [1]/[2] hub chunks by destination / source, [4] undirected, [5] unmatched
-        self._err = torch.zeros(8, dtype=torch.int32, device=dev)
+        pair_build = os.environ.get("GSAT_CSR_PAIR", "1") != "0"
+        # gsat_build_csr_pair zeroes words [0, 4) itself; [4, 6) are zeroed by the reverse-permutation call that owns them
+        self._err = (torch.empty if pair_build else torch.zeros)(8, dtype=torch.int32, device=dev)
+        self._err3_fresh = True
         # Both CSRs -- by destination (the forward aggregation order) and by source (the transposed structure of every
         # backward) -- their long-row (hub) chunk lists (empty for molecule-like graphs, built without a host sync), the
         # by-source-slot -> by-destination-slot map and int32 copies of the two edge_index rows: one library call, one sort.
@@ -321,7 +324,9 @@ class BatchIndex:
         key = (batch.data_ptr(), batch._version, int(batch.shape[0]))
         seg = self._graphs.get(key)
         if seg is None:
-            self._err[3:4].zero_()                 # the order / range counter belongs to the batch vector being registered
+            if not self._err3_fresh:
+                self._err[3:4].zero_()             # the order / range counter belongs to the batch vector being registered
+            self._err3_fresh = False
             seg = GraphSegments(self, batch, num_graphs)
             self._graphs = {key: seg}
             self._checked = False                  # the next host-side decision re-reads the status words, now including [3]

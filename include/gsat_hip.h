@@ -66,7 +66,7 @@ int gsat_build_csr(const int64_t* rows, const int64_t* other, int64_t num_edges,
  * identical to two gsat_build_csr calls (same stable order); the point is half the dependent launches per fresh batch.
  * edge_index [2,E] int64 (row 0 = source, row 1 = target).  replaces: the scatter index of MessagePassing.propagate
  * (src/models/conv_layers.py:21,44,163) for a whole batch.  workspace: gsat_csr_pair_workspace_bytes(E, N).
- * err_flag: int32[4], zeroed by the caller: [0] += number of out-of-range node ids, [1] / [2] = number of hub chunks of the
+ * err_flag: int32[4], zeroed BY THE CALL (its first launch): [0] = number of out-of-range node ids, [1] / [2] = number of hub chunks of the
  * by-destination / by-source CSR (chunk_ptr_*[N]), so one small device->host read answers every host-side question.
  */
 size_t gsat_csr_pair_workspace_bytes(int64_t E, int64_t num_nodes);
