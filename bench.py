@@ -104,6 +104,18 @@ class HotPath:
         self.flat = FlatGradAllReduce(self.ext.parameters())
 
     def step(self):
+        self.compute()
+        self.reduce()
+
+    def reduce(self):
+        """The one collective of the step (N > 1): flat gradient all-reduce, enqueued behind the last backward kernel."""
+        if self.flat is not None:
+            self.flat.all_reduce(average=True, async_op=True)
+            self.flat.wait()
+
+    def compute(self):
+        """Everything of the step but the collective (this part is what a hipGraph captures, also for N > 1: the gradients land in the
+        flat buffer at fixed addresses)."""
         G, d, wl = self.G, self.data, self.wl
         if not self.reuse_index:
             G.clear_cache()                       # every step is a NEW batch: re-derive CSRs / reverse perm / segments
@@ -126,9 +138,6 @@ class HotPath:
             else:
                 outs.append(G.ops.masked_sum_aggregate(self.xs[l], index, edge_att, self.edge_emb[l] if self.gine else None))
         torch.autograd.backward(outs, self.gouts)
-        if self.flat is not None:
-            self.flat.all_reduce(average=True, async_op=True)
-            self.flat.wait()
 
 
 class FullStep:
@@ -441,7 +450,7 @@ def main():
                     help="capture the step into a hipGraph (torch.cuda.graph) and time replays; DEFAULT on one GPU for c1-c4: the fork's "
                          "loaders are unshuffled (src/utils/get_data_loaders.py:133,141), so every batch recurs with the same shape each epoch "
                          "and a per-batch graph is what a training loop would replay; the index is still rebuilt inside every replay")
-    ap.add_argument("--eager", dest="graph", action="store_false", help="plain eager launches (the default for the c5 workloads and --gpus > 1)")
+    ap.add_argument("--eager", dest="graph", action="store_false", help="plain eager launches (the default for the c5 workloads and for N > 1)")
     ap.add_argument("--sync-free", action="store_true", help="eager launches, but no device->host read inside the step (dp_gsat_amd.set_sync_free)")
     ap.add_argument("--roofline-only", action="store_true", help="only run the aggregation-kernel roofline leg (for rocprofv3 --pmc passes)")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only to rehearse N>1 on one GPU)")
@@ -459,6 +468,8 @@ def main():
         # launch-bound batches (c1, c2, c4: 60-70 launches of a few microseconds) replay as one hipGraph.  c3 issues ~110 launches in
         # ~0.9 ms of host time against ~0.95 ms of GPU time: eager it measures the same on an idle host (0.965 ms) and 5-13 % worse on a
         # loaded one (tools/host_time_c3.py, profiles/r02_summary.md), so it replays as a graph too; c5 is GPU-bound by a wide margin
+        # N > 1 stays eager by default: graph replay per rank + an eager RCCL all-reduce behind it (`--graph` under torchrun does exactly
+        # that) could only be rehearsed with two gloo ranks sharing one GPU, never on a multi-GPU node
         args.graph = world == 1 and "RANK" not in os.environ and args.workload in ("c1", "c2", "c3", "c4") and not args.sync_free
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     # under torchrun (RANK set) the process group is initialised even at world size 1, so the RCCL path can be rehearsed on one GPU
@@ -511,7 +522,20 @@ def main():
 
     import dp_gsat_amd as G
     G.set_sync_free(bool(args.graph or args.sync_free))    # graph mode: no host read-backs inside the step, so it is capturable
-    step_fn = captured(hot.step) if args.graph else hot.step
+    if args.graph and distributed:
+        try:
+            replay = captured(hot.compute)        # everything but the collective; the gradients land in the flat buffer at fixed addresses
+
+            def step_fn():
+                replay()
+                hot.reduce()
+        except Exception as exc:                  # a backend that does not tolerate captures next to its communicator: measure eagerly
+            print(f"[bench] rank {rank}: capture failed ({exc}); falling back to eager launches", file=sys.stderr)
+            args.graph = False
+            G.set_sync_free(bool(args.sync_free))
+            step_fn = hot.step
+    else:
+        step_fn = captured(hot.step) if args.graph else hot.step
     dt = timed(step_fn, args.steps, args.warmup, dev, distributed)
     e_local = torch.tensor([float(data.num_edges), float(data.num_nodes)], dtype=torch.float64, device=dev)
     if distributed:
@@ -524,7 +548,7 @@ def main():
     if not args.no_full_step:
         # the whole training step of C3 is GPU-bound by a wide margin (4.6 ms) and measures ~4 % better eager than captured (capturable
         # Adam, device-side seeds): unless a mode was asked for, only the launch-bound workloads replay it as a graph
-        full_graph = bool(args.graph) and (mode_given or args.workload != "c3")
+        full_graph = bool(args.graph) and (mode_given or args.workload != "c3") and not distributed      # N > 1: forward/backward, all-reduce, Adam stay eager
         G.set_sync_free(bool(full_graph or args.sync_free))
         fs = FullStep(wl, data, x_dim, e_dim, dev, capturable=full_graph)
         if distributed:
