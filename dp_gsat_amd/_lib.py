@@ -143,12 +143,19 @@ def ptr(t):
     return t.data_ptr()
 
 
+_raw_stream = getattr(torch._C, "_cuda_getCurrentRawStream", None)
+
+
 def stream():
+    """Raw handle of torch's current stream on the current device.  (torch.cuda.current_stream() builds a Stream object per call:
+    ~10 us each, ~0.1 ms of a 1 ms C3 step.)"""
+    if _raw_stream is not None:
+        return _raw_stream(torch.cuda.current_device())
     return torch.cuda.current_stream().cuda_stream
 
 
 def call(name, *args):
-    lib = load()
+    lib = _lib if _lib is not None else load()
     rc = getattr(lib, name)(*args)
     if rc != 0:
         msg = lib.gsat_last_error()
