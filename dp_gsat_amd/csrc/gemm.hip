@@ -562,8 +562,11 @@ int gemm_splits(int64_t M, int64_t N, int64_t K, bool reduce_rows) {
     if (!reduce_rows) return 1;                       // only weight gradients (K = #rows) are split
     const int64_t tiles = ceil_div(M, 128) * ceil_div(N, 128);
     if (tiles >= 256 || K <= 4 * GK) return 1;
-    static const int div = getenv("GSAT_GEMM_SPLITK_SLABS") ? atoi(getenv("GSAT_GEMM_SPLITK_SLABS")) : 8;     // min 32-k slabs per split
+    static const int div_env = getenv("GSAT_GEMM_SPLITK_SLABS") ? atoi(getenv("GSAT_GEMM_SPLITK_SLABS")) : 0;     // min 32-k slabs per split
     static const int target = getenv("GSAT_GEMM_SPLITK_BLOCKS") ? atoi(getenv("GSAT_GEMM_SPLITK_BLOCKS")) : 768;
+    // a 64 x 64 weight gradient (GIN at H = 64) is ONE tile: with 8 slabs per split its 12 800 rows made 50 workgroups walking 8 slabs
+    // each (26 us for 0.1 GFLOP); 2 slabs per split give 200 short workgroups on 64 x 64 tiles
+    const int div = div_env > 0 ? div_env : (M <= 64 && N <= 64 ? 2 : 8);
     int64_t s = std::min<int64_t>(ceil_div(target, tiles), ceil_div(K, (int64_t)div * GK));
     return (int)std::max<int64_t>(1, std::min<int64_t>(s, 512));
 }
@@ -659,6 +662,7 @@ int gemm_f32(hipStream_t stream, bool a_t, bool b_t, int64_t M, int64_t N, int64
     const int splits = gemm_splits(M, N, K, a_t);
     int tm = 2, tn = 2;
     if (splits == 1) gemm_tile(M, N, K, &tm, &tn);
+    else if (!getenv("GSAT_GEMM_TILE")) { tm = M <= 64 ? 1 : 2; tn = N <= 64 ? 1 : 2; }       // split-K: do not pad a small output to 128 x 128
     // split-bf16: the per-tile staging (fp32 -> hi/lo, LDS planes) is what costs, so the largest tile wins even when it leaves
     // fewer workgroups than CUs x occupancy (51 639 x 128 x 1024: 57 us at 128x128 against 69 us at 128x64)
     if (split && splits == 1 && !getenv("GSAT_GEMM_TILE")) { tm = 2; tn = N > 64 ? 2 : 1; }
