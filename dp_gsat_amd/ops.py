@@ -640,7 +640,13 @@ class LinearFn(torch.autograd.Function):
 
 
 def linear(x, weight, bias=None):
-    """nn.functional.linear for 2-D fp32 ROCm inputs with 4-aligned widths; anything else goes to torch."""
-    if x.is_cuda and x.dim() == 2 and x.dtype == torch.float32 and x.shape[1] % 4 == 0 and weight.shape[0] % 4 == 0 and x.shape[0] > 0:
+    """nn.functional.linear for 2-D fp32 ROCm inputs with a 4-aligned output width; anything else goes to torch.  An input width that is
+    not a multiple of 4 (raw node / edge features: 10, 14, 1 columns) is zero-padded: the library's weight gradient for such a layer
+    -- a [out, 10] result reduced over 1e4..1e5 rows by ONE workgroup -- took 65 us per backbone pass at C2, the split-K kernel takes 5."""
+    if x.is_cuda and x.dim() == 2 and x.dtype == torch.float32 and weight.shape[0] % 4 == 0 and x.shape[0] > 0:
+        rem = x.shape[1] % 4
+        if rem:
+            x = torch.nn.functional.pad(x, (0, 4 - rem))
+            weight = torch.nn.functional.pad(weight, (0, 4 - rem))
         return LinearFn.apply(x, weight, bias)
     return torch.nn.functional.linear(x, weight, bias)
