@@ -597,7 +597,7 @@ def _gemm(a_t, b_t, M, N, K, A, lda, B, ldb, C, ldc, bias=None, split=True):
 
 # Linear products above this many FLOPs run on the split-bf16 MFMA path (gsat_gemm_bf16x3: 2-3x the fp32 library GEMM at the
 # backbone's shapes); smaller ones stay on the library (hipBLASLt via torch), which is as fast there
-_OWN_GEMM_FLOPS = 2e9
+_OWN_GEMM_FLOPS = float(os.environ.get("GSAT_OWN_GEMM_FLOPS", "2e9"))
 
 
 class LinearFn(torch.autograd.Function):
