@@ -213,3 +213,37 @@ def test_pna_hub_rows_chunked(dev, H, with_edge_attr, aggr, scalers):
     od2 = pna_aggregate(xd2, ix, ad2, ed.detach() if with_edge_attr else None, aggr, scalers, avg)
     od2.backward(go.to(dev))
     assert torch.equal(od, od2) and torch.equal(xd.grad, xd2.grad) and torch.equal(ad.grad, ad2.grad)
+
+
+@pytest.mark.parametrize("pattern", ["runs", "random", "giant", "ragged_tail"])
+def test_single_csr_counting_build(dev, pattern):
+    """gsat_build_csr (the edges-by-graph order of the edge-mode extractor) through the C ABI, counting path: long runs of one key (one
+    atomic per run of equal adjacent keys in a wave), unordered keys, a row of 3 chunks + a remainder (bitonic chunks merged by rank),
+    a key count that does not fill the last wave.  Bit-exact vs a stable argsort."""
+    from dp_gsat_amd._lib import call, ptr, stream
+    from dp_gsat_amd.graph_index import call_size
+    rng = np.random.default_rng(len(pattern))
+    R = 300
+    if pattern == "runs":
+        rows = np.repeat(np.arange(R), rng.integers(0, 90, R))
+    elif pattern == "random":
+        rows = rng.integers(0, R, 20_000)
+    elif pattern == "giant":
+        rows = np.concatenate([rng.integers(0, R, 3000), np.full(3 * 4096 + 777, 17)])
+        rows = rows[rng.permutation(rows.size)]
+    else:
+        rows = np.sort(rng.integers(0, R, 64 * 7 + 5))
+    E = rows.size
+    other = rng.integers(0, 1000, E)
+    rows_d, other_d = torch.from_numpy(rows).to(dev), torch.from_numpy(other).to(dev)
+    rowptr = torch.empty(R + 1, dtype=torch.int32, device=dev)
+    other_sorted, perm = torch.empty(E, dtype=torch.int32, device=dev), torch.empty(E, dtype=torch.int32, device=dev)
+    err = torch.zeros(1, dtype=torch.int32, device=dev)
+    wb = max(call_size("gsat_csr_workspace_bytes", E, R), 256)
+    ws = torch.empty(wb, dtype=torch.uint8, device=dev)
+    call("gsat_build_csr", ptr(rows_d), ptr(other_d), E, R, ptr(rowptr), ptr(other_sorted), ptr(perm), ptr(err), ptr(ws), wb, stream())
+    order = np.argsort(rows, kind="stable")
+    assert int(err.item()) == 0
+    assert np.array_equal(rowptr.cpu().numpy(), np.concatenate([[0], np.cumsum(np.bincount(rows, minlength=R))]))
+    assert np.array_equal(perm.cpu().numpy(), order)
+    assert np.array_equal(other_sorted.cpu().numpy(), other[order])
