@@ -433,9 +433,12 @@ def cpu_baseline(wl, name, seed, sample_graphs=0, warmup=3, steps=10, budget_s=1
 
 
 def main():
-    if os.environ.get("GSAT_BENCH_WATCHDOG"):          # debugging aid: dump every thread's stack and exit if the run takes longer than this many seconds
+    # dump every thread's stack and exit if the run takes longer than this many seconds (GSAT_BENCH_WATCHDOG); on by default for N > 1,
+    # where a rank that misses a collective would otherwise sit silently until the launcher's own timeout (N > 1 runs take < 2 minutes)
+    watchdog = os.environ.get("GSAT_BENCH_WATCHDOG", "540" if int(os.environ.get("WORLD_SIZE", "1")) > 1 else "")
+    if watchdog and float(watchdog) > 0:
         import faulthandler
-        faulthandler.dump_traceback_later(float(os.environ["GSAT_BENCH_WATCHDOG"]), exit=True)
+        faulthandler.dump_traceback_later(float(watchdog), exit=True)
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=None, help="timed steps (default 200; 10 for the c5 workloads)")
