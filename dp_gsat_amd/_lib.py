@@ -96,7 +96,8 @@ class AttnArgs(ctypes.Structure):
                 ("W1", P), ("b1", P), ("W2", P), ("b2", P), ("W3", P), ("b3", P),
                 ("emb", P), ("mask1", P), ("mask2", P), ("u", P),
                 ("P", P), ("Q", P), ("a1", P), ("h2", P), ("stats", P), ("logits", P), ("att", P),
-                ("fwd_workspace", P), ("fwd_workspace_bytes", SZ), ("seed_dev", P), ("noise_philox", I32)]
+                ("fwd_workspace", P), ("fwd_workspace_bytes", SZ), ("seed_dev", P), ("noise_philox", I32), ("fused", I32),
+                ("node_ptr", P)]
 
 
 class AttnGrads(ctypes.Structure):

@@ -11,6 +11,7 @@
 //     in the kernel when no tensor is given), InstanceNorm backward, deterministic column sums.
 //   * all reductions run in a fixed order (no float atomics): results are bitwise reproducible.
 #include "common.h"
+#include "attn_fused.h"
 #include <cstdlib>
 
 namespace gsat {
@@ -661,7 +662,7 @@ static int check_args(const gsat_attn_args* a, const char* who) {
     GSAT_REQUIRE(a->p_drop >= 0.f && a->p_drop < 1.f, GSAT_ERR_ARG, "%s: dropout p must be in [0,1)", who);
     if (a->M == 0) return GSAT_OK;
     GSAT_REQUIRE(a->emb && a->W1 && a->b1 && a->W2 && a->b2 && a->W3 && a->b3 && a->seg_ptr && a->row_seg, GSAT_ERR_ARG, "%s: null input", who);
-    GSAT_REQUIRE(a->P && a->a1 && a->h2 && a->stats && a->logits, GSAT_ERR_ARG, "%s: null output/saved buffer", who);
+    GSAT_REQUIRE(a->P && a->h2 && a->stats && a->logits, GSAT_ERR_ARG, "%s: null output/saved buffer", who);
     if (a->edge_mode) GSAT_REQUIRE(a->src && a->dst && a->Q, GSAT_ERR_ARG, "%s: edge mode needs src, dst, Q", who);
     else GSAT_REQUIRE(a->M == a->N, GSAT_ERR_ARG, "%s: node mode needs M == N", who);
     return GSAT_OK;
@@ -688,6 +689,11 @@ int gsat_attn_fwd(const gsat_attn_args* a, void* stream_) {
     int rc = check_args(a, "gsat_attn_fwd");
     if (rc) return rc;
     if (a->M == 0) return GSAT_OK;
+    {
+        FusedGeom fg;
+        if (attn_fused_eligible(a, &fg)) return attn_fused_fwd(stream, a, fg);        // one launch, whole graphs per workgroup (attn_fused.hip)
+    }
+    GSAT_REQUIRE(a->a1, GSAT_ERR_ARG, "gsat_attn_fwd: the staged pipeline needs the a1 buffer");
     const int64_t M = a->M, N = a->N, G = a->G;
     const int H = a->H, C1 = a->C1, C2 = a->C2;
     float* mean1 = a->stats;
@@ -747,6 +753,8 @@ int gsat_attn_fwd(const gsat_attn_args* a, void* stream_) {
 
 size_t gsat_attn_fwd_workspace_bytes(const gsat_attn_args* a) {
     if (!a) return 0;
+    FusedGeom fg;
+    if (attn_fused_eligible(a, &fg)) return fused_ws_bytes(fg, a->G);
     const int Z = seg_slices(a->M, a->G);
     return Z > 1 ? (size_t)a->G * Z * std::max(a->C1, a->C2) * sizeof(float) : 0;
 }

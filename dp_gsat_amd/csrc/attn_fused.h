@@ -1,0 +1,35 @@
+// Fused attention-extractor kernels (attn_fused.hip): geometry + entry points shared with attn.hip.
+#pragma once
+#include "common.h"
+
+namespace gsat {
+
+constexpr int F_GT = 16;            // graphs per tile (LDS statistics arrays are [2][F_GT][width])
+
+struct FusedGeom {
+    int H, C1, C2, C2p;
+    int CH, NCH;                    // layer-1 output channels per chunk (128 node / 64 edge), chunks
+    int S1, S2;                     // float4 steps of a B fragment stream: layer 1 (H/8), layer 2 (CH/8)
+    int NCB2;                       // 32-column blocks of layer 2
+    int NRB, RM, RX;                // row blocks per row wave, MLP rows per tile (64*NRB), embedding rows per tile
+    int LDX, LDU, LDT, LDH, SW;     // LDS row strides (floats) and the width of a statistics row
+    int offU, offT, offS, offMeta;  // LDS offsets (floats)
+    int lds_bytes;
+};
+
+bool fused_geometry(int H, int C1, int C2, bool edge, FusedGeom* out);
+size_t fused_ws_bytes(const FusedGeom& g, int64_t G);
+bool attn_fused_eligible(const gsat_attn_args* a, FusedGeom* g);
+int attn_fused_fwd(hipStream_t stream, const gsat_attn_args* a, const FusedGeom& g);
+
+#ifdef __HIPCC__
+// dropout keep-mask of 4 consecutive channels: explicit tensor, or Philox keyed by (seed, layer, row, column) -- the same draw as
+// gsat_philox_keep_mask and the unfused kernels of attn.hip
+__device__ __forceinline__ float4 keep4f(const float* mask, SeedRef sref, int layer, int row, int c, int C, float p, bool training) {
+    if (!training || p <= 0.f) return make_float4(1.f, 1.f, 1.f, 1.f);
+    if (mask) return ld4(mask + (size_t)row * C + c);
+    return philox_keep4(sref.get(), layer, row, c, p);
+}
+#endif
+
+}  // namespace gsat

@@ -226,6 +226,8 @@ def _attn_args(emb, params, index, segments, edge_mode, training, p, seed, mask1
     a.P, a.Q, a.a1, a.h2, a.stats, a.logits, a.att = ptr(P), ptr(Q), ptr(a1), ptr(h2), ptr(stats), ptr(logits), ptr(att)
     a.seed_dev = ptr(seed_dev)
     a.noise_philox = int(bool(noise_philox) and u is None)
+    a.fused = 0              # library default (staged pipeline; GSAT_ATTN_FUSED=1 opts into the one-launch forward)
+    a.node_ptr = ptr(segments.node_ptr)
     return a
 
 

@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define GSAT_ABI_VERSION 2
+#define GSAT_ABI_VERSION 3
 
 #define GSAT_OK 0
 #define GSAT_ERR_HIP (-1)        /* a HIP runtime call failed */
@@ -402,6 +402,9 @@ typedef struct gsat_attn_args {
     const uint64_t* seed_dev;  /* nullable DEVICE word overriding `seed` (hipGraph replays: new dropout mask per replay) */
     int32_t noise_philox;      /* != 0 with `training` and u == NULL: draw the concrete sampler's u in the kernel (Philox stream 4 of
                                   `seed`, row-keyed) instead of reading a tensor -- the reference's uniform_ launch (example/gsat.py:96) */
+    int32_t fused;             /* 1: take the fused one-launch forward (whole graphs per workgroup, attn_fused.hip) when the shapes allow it;
+                                  0: library default (the staged pipeline unless GSAT_ATTN_FUSED=1 is set); -1: never */
+    const int32_t* node_ptr;   /* [G+1] node segments of the batch; edge mode needs it for the fused forward (NULL: staged pipeline) */
 } gsat_attn_args;
 
 typedef struct gsat_attn_grads {

@@ -29,13 +29,13 @@ def test_library_exports_every_declared_symbol():
     for name in sorted(decl):
         assert hasattr(lib, name), f"{name} declared in include/gsat_hip.h but not exported"
     assert decl == set(_lib.SIGNATURES), decl ^ set(_lib.SIGNATURES)
-    assert _lib.load().gsat_abi_version() == 2
+    assert _lib.load().gsat_abi_version() == 3
 
 
 def test_ctypes_structs_match_header_layout():
     from dp_gsat_amd._lib import AttnArgs, AttnGrads
-    # 3 i64, 5 i32, float, u64, 24 pointers, size_t, then noise_philox (i32) + 4 bytes of tail padding
-    assert ctypes.sizeof(AttnArgs) == 3 * 8 + 5 * 4 + 4 + 8 + 24 * 8 + 8 + 8
+    # 3 i64, 5 i32, float, u64, 24 pointers, size_t, then noise_philox + fused (2 x i32), node_ptr (ABI 3)
+    assert ctypes.sizeof(AttnArgs) == 3 * 8 + 5 * 4 + 4 + 8 + 24 * 8 + 8 + 8 + 8
     assert ctypes.sizeof(AttnGrads) == 16 * 8 + 8
 
 
