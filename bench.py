@@ -203,9 +203,10 @@ def timed(step_fn, steps, warmup, dev, distributed):
 # ------------------------------------------------------------------------------------------------
 def aggregation_roofline(wl, data, dev, reps=30, rounds=5, step_fn=None):
     """Forward masked-aggregation kernel and the WHOLE aggregation backward (every launch it takes), priced on compulsory bytes.
-    `us_per_launch` = HIP events around back-to-back launches on torch's stream (the launch stream) with the queue kept busy: the
-    kernel's best case.  `in_step_us` = the same launch timed right behind a real hot-path step (cold caches, the state the
-    kernel meets inside the step); rocprofv3's per-kernel average of the bench command (profiles/) agrees with that one."""
+    `us_per_launch` / `frac` = the launch timed with HIP events (torch's stream = the launch stream) right behind a real hot-path step
+    (cold caches, the state the kernel meets inside the timed region); rocprofv3's per-kernel average of the bench command
+    (profiles/) agrees with that one.  `us_isolated` / `frac_isolated` = back-to-back launches with the queue kept busy: the kernel's
+    best case."""
     import dp_gsat_amd as G
     from dp_gsat_amd._lib import call, ptr, stream
     N, E, H = data.num_nodes, data.num_edges, wl["H"]
@@ -276,11 +277,15 @@ def aggregation_roofline(wl, data, dev, reps=30, rounds=5, step_fn=None):
             bwd_traffic = rec.get("backward_traffic_bytes")
     except (OSError, ValueError, KeyError):
         pass
-    out = dict(bound="hbm", kernel=kname, achieved=round(achieved, 1), peak=HBM_PEAK_GBS, unit="GB/s",
-               frac=round(achieved / HBM_PEAK_GBS, 4), traffic=traffic, alg_bytes_per_launch=int(alg_bytes),
-               us_per_launch=round(t * 1e6, 2), nodes=N, edges=E)
-    if t_in:
-        out.update(in_step_us=round(t_in * 1e6, 2), frac_in_step=round(alg_bytes / t_in / 1e9 / HBM_PEAK_GBS, 4))
+    # `achieved` / `frac` / `us_per_launch` are the IN-STEP figures (one launch timed with HIP events right behind a real hot-path step: cold
+    # caches, the state the kernel meets inside the timed region; rocprofv3's in-step average of the same command is in profiles/ and
+    # agrees within a dispatch gap).  The back-to-back best case -- the number round 2 reported as `frac` -- stays as `*_isolated`.
+    t_rep = t_in if t_in else t
+    out = dict(bound="hbm", kernel=kname, achieved=round(alg_bytes / t_rep / 1e9, 1), peak=HBM_PEAK_GBS, unit="GB/s",
+               frac=round(alg_bytes / t_rep / 1e9 / HBM_PEAK_GBS, 4), traffic=traffic, alg_bytes_per_launch=int(alg_bytes),
+               us_per_launch=round(t_rep * 1e6, 2), timing="in_step" if t_in else "isolated",
+               us_isolated=round(t * 1e6, 2), achieved_isolated=round(achieved, 1), frac_isolated=round(achieved / HBM_PEAK_GBS, 4),
+               nodes=N, edges=E)
     # what plain streaming passes over a buffer of the kernel's output size reach on this box (quote the vendor
     # peak AND the measured rate): a write-only fill and a device-to-device copy (bytes = read + write)
     y2 = torch.empty_like(y)
@@ -324,10 +329,10 @@ def aggregation_roofline(wl, data, dev, reps=30, rounds=5, step_fn=None):
         bname = "k_aggr_sum_bwd"
     tb = time_launches(launch_bwd)
     tb_in = time_in_step(launch_bwd)
-    out["backward"] = dict(kernels=bname, achieved=round(bwd_bytes / tb / 1e9, 1), frac=round(bwd_bytes / tb / 1e9 / HBM_PEAK_GBS, 4),
-                           compulsory_bytes=int(bwd_bytes), us_all_launches=round(tb * 1e6, 2), traffic=bwd_traffic)
-    if tb_in:
-        out["backward"].update(in_step_us=round(tb_in * 1e6, 2), frac_in_step=round(bwd_bytes / tb_in / 1e9 / HBM_PEAK_GBS, 4))
+    tb_rep = tb_in if tb_in else tb
+    out["backward"] = dict(kernels=bname, achieved=round(bwd_bytes / tb_rep / 1e9, 1), frac=round(bwd_bytes / tb_rep / 1e9 / HBM_PEAK_GBS, 4),
+                           compulsory_bytes=int(bwd_bytes), us_all_launches=round(tb_rep * 1e6, 2), timing="in_step" if tb_in else "isolated",
+                           us_isolated=round(tb * 1e6, 2), frac_isolated=round(bwd_bytes / tb / 1e9 / HBM_PEAK_GBS, 4), traffic=bwd_traffic)
     return out
 
 
@@ -395,13 +400,16 @@ def cpu_baseline(wl, name, seed, sample_graphs=0, warmup=3, steps=10, budget_s=1
 
     default_threads = torch.get_num_threads()
     physical = max(1, (os.cpu_count() or 2) // 2)            # SMT host: logical / 2
-    thread_settings = sorted({5, physical})
+    # 5 = the reference's own setting; all physical cores per SURVEY 8d; 16 / 32 / 64 so that one datum is not an oversubscription artefact
+    thread_settings = sorted({5, physical} | {t for t in (16, 32, 64) if t <= physical})
+    load0 = os.getloadavg() if hasattr(os, "getloadavg") else (None, None, None)
     d = full if not sample_graphs else take_graphs(full, range(min(sample_graphs, full.num_graphs)))
     step, N, E = build(d)
     torch.set_num_threads(5)
     t0 = time.perf_counter(); step(); t_probe = time.perf_counter() - t0      # probe at the reference's thread count
-    if not sample_graphs and t_probe * (warmup + steps) > budget_s / 2 and full.num_graphs > 1:
-        keep = max(1, int(full.num_graphs * (budget_s / 2) / (t_probe * (warmup + steps))))
+    share = budget_s / len(thread_settings)
+    if not sample_graphs and t_probe * (warmup + steps) > share and full.num_graphs > 1:
+        keep = max(1, int(full.num_graphs * share / (t_probe * (warmup + steps))))
         d = take_graphs(full, range(keep))
         step, N, E = build(d)
     results, measured = {}, {}
@@ -410,14 +418,14 @@ def cpu_baseline(wl, name, seed, sample_graphs=0, warmup=3, steps=10, budget_s=1
         t_begin = time.perf_counter()
         for i in range(warmup):
             step()
-            if time.perf_counter() - t_begin > budget_s / 8:
+            if time.perf_counter() - t_begin > budget_s / (4 * len(thread_settings)):
                 break                                   # a very slow setting (oversubscribed cores): do not burn the budget on warm-up
         ts = []
         for i in range(steps):
             t0 = time.perf_counter()
             step()
             ts.append(time.perf_counter() - t0)
-            if len(ts) >= 3 and time.perf_counter() - t_begin > budget_s / 2:
+            if len(ts) >= 3 and time.perf_counter() - t_begin > budget_s / len(thread_settings):
                 break
         results[threads] = float(np.median(ts))
         measured[threads] = len(ts)
@@ -429,7 +437,8 @@ def cpu_baseline(wl, name, seed, sample_graphs=0, warmup=3, steps=10, budget_s=1
                        f"{warmup} warm-up + median of {steps} steps per thread setting, {t * 1e3:.1f} ms/step",
                 sample_fraction=round(frac, 4), warmup=warmup, steps=steps, steps_measured={str(k): v for k, v in measured.items()},
                 by_threads={str(k): round(E / v / 1e6, 5) for k, v in results.items()}, physical_cores=physical,
-                host_cpus=os.cpu_count(), cpu_model=_cpu_model())
+                host_cpus=os.cpu_count(), cpu_model=_cpu_model(), host_loadavg_before=[round(x, 1) for x in load0 if x is not None],
+                host_loadavg_after=[round(x, 1) for x in os.getloadavg()] if hasattr(os, "getloadavg") else None)
 
 
 def main():
@@ -448,6 +457,8 @@ def main():
     ap.add_argument("--reuse-index", action="store_true", help="keep the per-batch bookkeeping cached across steps")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-full-step", action="store_true")
+    ap.add_argument("--no-exact-rerun", action="store_true", help="skip the second timing with the extractor's backward products on exact fp32")
+    ap.add_argument("--no-roofline", action="store_true", help="skip the roofline leg (profiles of the timed region without its extra launches)")
     ap.add_argument("--cpu-sample-graphs", type=int, default=0)
     ap.add_argument("--graph", dest="graph", action="store_true", default=None,
                     help="capture the step into a hipGraph (torch.cuda.graph) and time replays; DEFAULT on one GPU for c1-c4: the fork's "
@@ -547,6 +558,19 @@ def main():
     ms = dt / args.steps * 1e3
     value = e_total / (dt / args.steps) / 1e6
 
+    # the same step with the extractor's four backward products on exact fp32 MFMA instead of split-bf16 (GSAT_ATTN_BWD_SPLIT=0),
+    # measured in the same process so that the line says what the default costs / buys
+    value_exact = ms_exact = None
+    if world == 1 and not distributed and not args.no_exact_rerun:
+        os.environ["GSAT_ATTN_BWD_SPLIT"] = "0"
+        try:
+            step_exact = captured(hot.step) if args.graph else hot.step
+            dte = timed(step_exact, args.steps, max(args.warmup // 2, 2), dev, False)
+            ms_exact = dte / args.steps * 1e3
+            value_exact = e_total / (dte / args.steps) / 1e6
+        finally:
+            del os.environ["GSAT_ATTN_BWD_SPLIT"]
+
     full = None
     if not args.no_full_step:
         # the whole training step of C3 is GPU-bound by a wide margin (4.6 ms) and measures ~4 % better eager than captured (capturable
@@ -561,14 +585,16 @@ def main():
         fsteps = max(args.steps // 2, 3)
         full = dict(value=round(e_total / (fdt / fsteps) / 1e6, 3), unit="million edges/s", ms_per_step=round(fdt / fsteps * 1e3, 3),
                     what="whole GSAT training step: 2 backbone passes + extractor + losses + backward + Adam (+ all-reduce)", hipgraph=full_graph,
-                    gemm_precision="extractor: fp32 MFMA (exact); backbone Linear layers >= 2 GFLOP: bf16x3 (split-bf16, fp32 accumulate)")
+                    gemm_precision="extractor forward products: fp32 MFMA (exact); extractor backward products (da1, demb, dW1, dW2) and backbone "
+                                   "Linear layers >= 2 GFLOP (forward, dx, dW): bf16x3 (split-bf16 hi*hi + hi*lo + lo*hi, fp32 accumulate, rel. error ~1e-5); "
+                                   "smaller Linear layers: library fp32 GEMM")
 
     G.set_sync_free(False)
     roof, cpu = None, None
     if rank == 0:
         hot.reuse_index = True
         hot.flat = None          # rank 0 alone runs this leg: its in-step timing must not enter the gradient all-reduce (the other ranks wait at the barrier below)
-        roof = aggregation_roofline(wl, data, dev, step_fn=hot.step)
+        roof = None if args.no_roofline else aggregation_roofline(wl, data, dev, step_fn=hot.step)
         if not args.no_cpu_baseline and world == 1:          # reported at N=1 only
             cpu = cpu_baseline(wl, args.workload, args.seed, args.cpu_sample_graphs)
     if distributed:
@@ -579,6 +605,11 @@ def main():
             "metric": "million edges/s (attn+sample+aggregate fwd+bwd)", "value": round(value, 3), "unit": "million edges/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms, 4),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "gemm_precision": "timed region: extractor forward products (P|Q, h2) exact fp32 MFMA; extractor backward products (da1, demb, dW1, dW2) "
+                              "split-bf16 x3 (hi*hi + hi*lo + lo*hi on bf16 MFMA, fp32 accumulate, rel. error ~1e-5 of each gradient's scale); "
+                              "aggregation kernels fp32 VALU; no other GEMM in scope A",
+            "value_fp32_exact": None if value_exact is None else round(value_exact, 3),
+            "ms_per_step_fp32_exact": None if ms_exact is None else round(ms_exact, 4),
             "config": {"workload": wl["desc"], "graphs_per_gpu": wl["graphs"], "nodes_total": int(n_total), "edges_total": int(e_total),
                        "hidden": wl["H"], "layers": wl["L"], "attention": "edge" if wl["edge_att"] else "node",
                        "parallelism": f"dp{world}", "index_rebuilt_every_step": not args.reuse_index, "hipgraph": bool(args.graph), "sync_free": bool(args.graph or args.sync_free)},

@@ -34,7 +34,8 @@ struct GemmWs { float* ptr; size_t floats; };
 // turns the same perturbation of h into ~3e2 x 1e-5 of the normalised value, so they stay exact fp32.
 static int gemm_rm(hipStream_t stream, bool ta, bool tb, int64_t M, int64_t N, int64_t K, const float* A, int64_t lda, const float* B,
                    int64_t ldb, float beta, float* C, int64_t ldc, GemmWs ws = {nullptr, 0}, bool split_ok = false) {
-    static const bool bwd_split = !(getenv("GSAT_ATTN_BWD_SPLIT") && atoi(getenv("GSAT_ATTN_BWD_SPLIT")) == 0);
+    const char* env = getenv("GSAT_ATTN_BWD_SPLIT");                    // read per call: bench.py times both settings in one process
+    const bool bwd_split = !(env && atoi(env) == 0);
     return gemm_f32(stream, ta, tb, M, N, K, A, lda, B, ldb, C, ldc, nullptr, beta != 0.f, ws.ptr, ws.floats, split_ok && bwd_split);
 }
 

@@ -707,7 +707,7 @@ __global__ void k_pna_tiles(const int32_t* __restrict__ node_ptr, const int32_t*
         start = (int)p;
         if (node_seg) {             // pull the window start back to the start of the graph that contains row p, at most `slack` rows
             const int g0 = node_ptr[node_seg[p]];
-            start = max(g0, (int)p - slack);
+            start = min((int)p, max(g0, (int)p - slack));      // never past p, whatever node_ptr holds for an unsorted batch vector: windows stay <= RCAP rows
         }
     }
     desc[t] = make_int4(start, rowptr[start], rowptr_src[start], 0);
@@ -925,7 +925,8 @@ __global__ void k_pna_spill_rows(const int4* __restrict__ desc, int TN, int TE, 
     }
     if (flag) {
         const int idx = atomicAdd(spill_count, 1);
-        if (idx < num_rows) spill_rows[idx] = j;            // cannot overflow as long as the counter starts at 0; stay in bounds regardless
+        if (idx < num_rows) spill_rows[idx] = j;            // cannot overflow as long as the counter starts at 0; stay in bounds regardless.  The counter keeps
+                                                            // counting, so *spill_count > num_rows IS the overflow record (tests assert it never happens)
     }
 }
 

@@ -114,8 +114,12 @@ class FlatGradAllReduce:
         self._bind()
         if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(self.group) == 1:
             return None
-        self._work = dist.all_reduce(self.flat, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
-        self._scale = 1.0 / dist.get_world_size(self.group) if average else 1.0
+        # RCCL averages inside the collective (ncclAvg): no separate `flat.mul_(1 / world)` launch behind it; gloo (CPU rehearsals) has
+        # no AVG, so it keeps SUM + one scale.  With `global_loss_weights(..., sum_reduce=True)` the 1 / world factor is folded into the
+        # loss weights instead and `average=False` needs neither.
+        use_avg = average and dist.get_backend(self.group) == "nccl"
+        self._work = dist.all_reduce(self.flat, op=dist.ReduceOp.AVG if use_avg else dist.ReduceOp.SUM, group=self.group, async_op=True)
+        self._scale = 1.0 / dist.get_world_size(self.group) if (average and not use_avg) else 1.0
         if async_op:
             return self._work
         self.wait()
@@ -129,13 +133,14 @@ class FlatGradAllReduce:
                 self.flat.mul_(self._scale)
 
 
-def global_loss_weights(num_local_graphs: int, num_local_rows: int, device, process_group=None):
+def global_loss_weights(num_local_graphs: int, num_local_rows: int, device, process_group=None, sum_reduce: bool = False):
     """(G_local/G_global * W, M_local/M_global * W): scaling the local BCE (mean over graphs) and info loss (mean
     over attention rows) by these and AVERAGING gradients over the W ranks reproduces the single-process loss at
-    the same global batch."""
+    the same global batch.  ``sum_reduce=True`` drops the factor W: the weights then go with a SUM all-reduce
+    (``FlatGradAllReduce.all_reduce(average=False)``), i.e. the 1 / world scale is folded into the loss and costs no launch."""
     if not (dist.is_available() and dist.is_initialized()):
         return 1.0, 1.0
-    W = dist.get_world_size(process_group)
+    W = 1 if sum_reduce else dist.get_world_size(process_group)
     t = torch.tensor([float(num_local_graphs), float(num_local_rows)], dtype=torch.float64, device=device)
     dist.all_reduce(t, group=process_group)
     tot = t.tolist()

@@ -63,10 +63,24 @@ class BatchNorm1d(nn.BatchNorm1d):
 
     def forward(self, x, fused_relu: bool = False, residual=None, dropout_p: float = 0.0):
         """``residual`` / ``dropout_p``: y = dropout_p(act(BN(x)) + residual) in the same kernels (the PNA layer tail)."""
-        hip_ok = (x.is_cuda and x.dim() == 2 and x.dtype == torch.float32 and self.affine and x.shape[1] % 4 == 0
-                  and (self.training or self.track_running_stats) and self.momentum is not None and x.shape[0] > 0)
+        shape_ok = (x.is_cuda and x.dim() == 2 and x.dtype == torch.float32 and self.affine and x.shape[1] % 4 == 0
+                    and (self.training or self.track_running_stats) and self.momentum is not None)
+        hip_ok = shape_ok and x.shape[0] > 0
         p = float(dropout_p) if self.training else 0.0
-        if not hip_ok:
+        sync = None
+        if (self.training or not self.track_running_stats) and self.sync_group is not None:
+            import torch.distributed as dist
+            if dist.is_available() and dist.is_initialized():
+                group = None if self.sync_group is True else self.sync_group
+                if dist.get_world_size(group) > 1:
+                    # global statistics were asked for: EVERY rank must enter the collectives of SyncBatchNormFn -- also a rank whose shard
+                    # has no rows (the kernels take N == 0: zero sums, no apply launch) -- and a shape the HIP path cannot take must not
+                    # silently fall back to per-rank statistics
+                    if not shape_ok:
+                        raise ValueError("BatchNorm1d with sync_group needs a 2-D fp32 ROCm input with affine parameters and a channel count "
+                                         f"that is a multiple of 4 (got {tuple(x.shape)}, {x.dtype}, device {x.device})")
+                    sync = (group,)
+        if not hip_ok and sync is None:
             y = super().forward(x)
             y = torch.relu(y) if fused_relu else y
             if residual is not None:
@@ -83,14 +97,10 @@ class BatchNorm1d(nn.BatchNorm1d):
                 seed_dev = torch.empty(1, dtype=torch.int64, device=x.device).random_()
             else:
                 seed = new_seed()
-        if training and self.sync_group is not None:
-            import torch.distributed as dist
-            if dist.is_available() and dist.is_initialized():
-                group = None if self.sync_group is True else self.sync_group
-                if dist.get_world_size(group) > 1:
-                    return SyncBatchNormFn.apply(x, self.weight, self.bias, self.running_mean if self.track_running_stats else None,
-                                                 self.running_var if self.track_running_stats else None, self.momentum, self.eps, fused_relu,
-                                                 residual, p, seed, seed_dev, group)
+        if sync is not None:
+            return SyncBatchNormFn.apply(x, self.weight, self.bias, self.running_mean if self.track_running_stats else None,
+                                         self.running_var if self.track_running_stats else None, self.momentum, self.eps, fused_relu,
+                                         residual, p, seed, seed_dev, sync[0])
         return BatchNormFn.apply(x, self.weight, self.bias, self.running_mean if self.track_running_stats else None,
                                  self.running_var if self.track_running_stats else None, training, self.momentum, self.eps, fused_relu,
                                  residual, p, seed, seed_dev)

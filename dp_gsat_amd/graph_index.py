@@ -212,8 +212,10 @@ class BatchIndex:
         """Sync-free mode never reads the status words inside the step.  The kernels are memory-safe on bad input (ids are
         clamped), but the caller still deserves the ValueError: validate each distinct batch ONCE, outside stream capture
         (the warm-up runs that precede a capture), and never again for the same tensors."""
-        key = (self.edge_index.data_ptr(), tuple(self.edge_index.shape), self.N,
-               tuple((k[0], k[2]) for k in self._graphs))
+        # keyed on the tensors' storage AND their versions: a new batch that lands on a recycled allocation of the same shape (or an
+        # in-place edit) is validated again
+        key = (self.edge_index.data_ptr(), self._key_tensor._version, tuple(self.edge_index.shape), self.N,
+               tuple(k for k in self._graphs))
         if key in _VALIDATED or torch.cuda.is_current_stream_capturing():
             return
         self._readback()
@@ -253,7 +255,9 @@ class BatchIndex:
         self._long = (vals[1] > 0, vals[2] > 0)
         if vals[1] > 0 or vals[2] > 0:
             _HUBS_SEEN[0] = True
-        self._checked = True
+        # a batch with bad ids stays "unchecked": every later host-side question about this cached index (long_rows, check(), the ops)
+        # reads the status words again and raises again, instead of running silently on clamped ids after the first ValueError
+        self._checked = vals[0] == 0 and vals[3] == 0
         if vals[0] != 0:
             raise ValueError("edge_index contains node ids outside [0, num_nodes)")
         if vals[3] != 0:

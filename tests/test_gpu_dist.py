@@ -108,7 +108,63 @@ def test_sharded_hip_step_matches_single_process(dev, backbone, edge_att):
     assert all(r[1] for r in res), res
 
 
-def test_bench_runs_with_two_ranks(dev):
+def _bn_worker(rank, world, port, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    import torch.distributed as dist
+    dev = torch.device("cuda:0")
+    torch.cuda.set_device(dev)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from dp_gsat_amd.encoders import BatchNorm1d
+        g = torch.Generator().manual_seed(5)
+        x_all = torch.randn(37, 16, generator=g).to(dev)
+        go_all = torch.randn(37, 16, generator=g).to(dev)
+        torch.manual_seed(1)
+        ref = BatchNorm1d(16).to(dev).train()
+        xr = x_all.clone().requires_grad_(True)
+        ref(xr, fused_relu=True).backward(go_all)
+        bn = BatchNorm1d(16).to(dev).train()
+        bn.load_state_dict(torch.nn.BatchNorm1d(16).state_dict())
+        bn.sync_group = True
+        # rank 1 holds NO rows (a last batch with fewer graphs than ranks): it must still enter every collective
+        x = (x_all if rank == 0 else x_all[:0]).clone().requires_grad_(True)
+        y = bn(x, fused_relu=True)
+        y.backward(go_all if rank == 0 else go_all[:0])
+        ok = True
+        if rank == 0:
+            ok = bool(torch.allclose(x.grad, xr.grad, atol=1e-5)) and bool(torch.allclose(bn.running_var, ref.running_var, atol=1e-6))
+        odd = BatchNorm1d(6).to(dev).train()
+        odd.sync_group = True
+        try:
+            odd(torch.randn(4, 6, device=dev))
+            ok = False                      # a width the HIP path cannot take must not fall back to per-rank statistics silently
+        except ValueError:
+            pass
+        q.put((rank, ok, tuple(y.shape)))
+    except Exception as e:
+        import traceback
+        q.put((rank, False, traceback.format_exc()))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_sync_batchnorm_with_an_empty_shard(dev):
+    """a rank whose shard has 0 rows used to take the torch path and skip the three all-reduces (the other ranks then hung)."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_bn_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=300) for _ in procs]
+    for p in procs:
+        p.join(timeout=120)
+    assert all(r[1] for r in res), res
+
+
+@pytest.mark.parametrize("mode", ["--eager", "--graph"])
+def test_bench_runs_with_two_ranks(dev, mode):
     """bench.py as the driver launches it for N > 1 (torch.distributed.run, one process per rank), here with two ranks sharing GPU 0 over
     gloo: the run must END (round 2 found rank 0's roofline leg re-entering the gradient all-reduce while the other rank sat at the
     closing barrier -- a hang at every N > 1) and print one JSON line for the whole job."""
@@ -121,11 +177,13 @@ def test_bench_runs_with_two_ranks(dev):
         env.pop(k, None)
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
            "--master-port", str(_free_port()), os.path.join(root, "bench.py"), "--gpus", "2", "--workload", "c1", "--steps", "5", "--warmup", "2",
-           "--no-cpu-baseline", "--backend", "gloo"]
+           "--no-cpu-baseline", "--backend", "gloo", mode]
     out = subprocess.run(cmd, cwd=root, env=env, capture_output=True, text=True, timeout=280)
     assert out.returncode == 0, out.stderr[-2000:]
     lines = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
     assert len(lines) == 1, out.stdout[-2000:]
     line = json.loads(lines[0])
     assert line["n_gpus"] == 2 and line["scaling"] == "weak" and line["value"] > 0 and line["roofline"]["frac"] > 0
-    assert line["config"]["hipgraph"] is False and line["full_step"]["hipgraph"] is False and line["full_step"]["ms_per_step"] > 0          # N > 1: eager by default
+    # --graph: every rank replays its captured step, the gradient all-reduce stays an eager call behind the replay (bench.py captured()); the
+    # full step (forward/backward, all-reduce, Adam) stays eager for N > 1 either way
+    assert line["config"]["hipgraph"] is (mode == "--graph") and line["full_step"]["hipgraph"] is False and line["full_step"]["ms_per_step"] > 0

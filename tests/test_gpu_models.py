@@ -272,9 +272,9 @@ def test_hipgraph_capture_of_a_training_step(dev):
             for _ in range(2):
                 step()
         torch.cuda.current_stream().wait_stream(side)
-        graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(graph):
-            step()
+        from tests.util import assert_no_memset_nodes, capture_with_dump
+        graph, dot = capture_with_dump(step)
+        assert_no_memset_nodes(dot, "captured GSAT training step")       # neither libgsat_hip nor the torch ops of the step may add one
         res = []
         for _ in range(3):
             graph.replay()

@@ -209,7 +209,9 @@ def test_pna_tiled_backward_under_back_to_back_graph_replays(dev):
         pna_aggregate(x, ix, att, None, aggr, ["identity"], avg).backward(go)
         dx_buf.copy_(x.grad)
         da_buf.copy_(att.grad)
+        held["spill"] = ix.pna_tiles(H)[5]          # [0] = number of listed spill sources, [1:] = the list (capacity N)
 
+    held = {}
     fn()
     torch.cuda.synchronize()
     want_dx, want_da = dx_buf.clone(), da_buf.clone()
@@ -221,15 +223,18 @@ def test_pna_tiled_backward_under_back_to_back_graph_replays(dev):
             for _ in range(3):
                 fn()
         torch.cuda.current_stream().wait_stream(side)
-        graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(graph):
-            fn()
+        from tests.util import assert_no_memset_nodes, capture_with_dump
+        graph, dot = capture_with_dump(fn)
+        assert_no_memset_nodes(dot, "PNA pipeline")
         for r in range(3):
             dx_buf.zero_(); da_buf.zero_()
             for _ in range(25):
                 graph.replay()
             torch.cuda.synchronize()
             assert torch.equal(dx_buf, want_dx) and torch.equal(da_buf, want_da), f"round {r}"
+            # the counter doubles as the overflow record: k_pna_spill_rows keeps counting past the list's capacity (and drops the
+            # entry), so a value above N would mean dropped spill rows, i.e. a silently wrong dx
+            assert 0 <= int(held["spill"][0]) <= N, f"round {r}: spill list overflowed"
     finally:
         G.set_sync_free(False)
         G.clear_cache()

@@ -23,3 +23,36 @@ def close(actual, ref, tol=TOL, ref64=None, what=""):
         target = r64
     err = (a - target).abs().max().item()
     assert err <= allowed, f"{what}: max abs err {err:.3e} > allowed {allowed:.3e} (scale {scale:.3e})"
+
+
+def capture_with_dump(fn):
+    """Capture one call of ``fn`` into a torch.cuda.CUDAGraph with debug mode on; returns (graph, dot text or None).  The dot text is
+    hipGraphDebugDotPrint's dump of the captured graph (None when this ROCm / torch build cannot produce it)."""
+    import os
+    import tempfile
+    graph = torch.cuda.CUDAGraph()
+    try:
+        graph.enable_debug_mode()
+    except Exception:
+        pass
+    with torch.cuda.graph(graph):
+        fn()
+    text = None
+    try:
+        path = os.path.join(tempfile.mkdtemp(), "graph.dot")
+        graph.debug_dump(path)
+        if os.path.exists(path) and os.path.getsize(path) > 0:
+            text = open(path, errors="replace").read()
+    except Exception:
+        text = None
+    return graph, text
+
+
+def assert_no_memset_nodes(dot_text, what=""):
+    """Round 2 found hipMemsetAsync nodes of a captured graph running out of order with the neighbouring replay's kernels (ROCm 7.2): the
+    library zeroes with kernels only, and no library call in a captured step may bring a memset node back."""
+    if dot_text is None:
+        return False
+    low = dot_text.lower()
+    assert "memset" not in low, f"{what}: the captured graph contains a memset node"
+    return True
