@@ -295,27 +295,49 @@ __global__ __launch_bounds__(256) void k_head_fwd(const float* __restrict__ h2, 
 }
 
 // dz[m] = dlogits[m] + datt[m] * att[m] * (1 - att[m]); the same launch zeroes the two bias gradients that are identically 0
-__global__ void k_dz(const float* __restrict__ dlogits, const float* __restrict__ datt, const float* __restrict__ att, int64_t M,
-                     float* __restrict__ dz, float* __restrict__ zero_a, int na, float* __restrict__ zero_b, int nb) {
+__global__ __launch_bounds__(256) void k_dz(const float* __restrict__ dlogits, const float* __restrict__ datt, const float* __restrict__ att,
+                                            int64_t M, float* __restrict__ dz, float* __restrict__ zero_a, int na, float* __restrict__ zero_b, int nb,
+                                            float* __restrict__ block_sum = nullptr /* [gridDim.x]: sum of the block's 256 dz values */) {
     int64_t m = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     const int64_t total = (int64_t)gridDim.x * blockDim.x;
     for (int64_t i = m; i < na; i += total) zero_a[i] = 0.f;
     for (int64_t i = m; i < nb; i += total) zero_b[i] = 0.f;
-    if (m >= M) return;
-    float v = dlogits ? dlogits[m] : 0.f;
-    if (datt) { float a = att[m]; v = fmaf(datt[m], a * (1.f - a), v); }
-    dz[m] = v;
+    float v = 0.f;
+    if (m < M) {
+        v = dlogits ? dlogits[m] : 0.f;
+        if (datt) { float a = att[m]; v = fmaf(datt[m], a * (1.f - a), v); }
+        dz[m] = v;
+    }
+    if (block_sum) {                      // fixed order: 64-lane butterfly, then the four waves in order
+        __shared__ float ws[4];
+        const float w = group_sum<64>(v);
+        if ((threadIdx.x & 63) == 0) ws[threadIdx.x >> 6] = w;
+        __syncthreads();
+        if (threadIdx.x == 0) block_sum[blockIdx.x] = ((ws[0] + ws[1]) + ws[2]) + ws[3];
+    }
 }
 
 // Backward statistics of layer 2 (through the head): per (graph, channel)
 //   S1 = mean_r dy2 , S2 = mean_r dy2*yhat2 , dw3 partial = sum_r dz * a2
 // APPLY (unsliced segments only): a second pass over the cache-hot rows writes dh2 = rstd2 * (dy2 - S1 - yhat2 * S2), i.e. k_dh2
+// dz of row m from the two upstream gradients (what k_dz writes): dlogits[m] + datt[m] * att[m] * (1 - att[m])
+struct DzSrc {
+    const float* dz;                 // precomputed (sliced segments), or NULL: evaluate from the three vectors below
+    const float *dlogits, *datt, *att;
+    __device__ __forceinline__ float get(int m) const {
+        if (dz) return dz[m];
+        float v = dlogits ? dlogits[m] : 0.f;
+        if (datt) { const float a = att[m]; v = fmaf(datt[m], a * (1.f - a), v); }
+        return v;
+    }
+};
+
 template <bool APPLY>
 __global__ __launch_bounds__(SB) void k_head_bwd_stats(const float* __restrict__ h2, const float* __restrict__ b2,
                                                        const int32_t* __restrict__ seg_ptr, const int32_t* __restrict__ order,
                                                        const float* __restrict__ mean, const float* __restrict__ rstd,
                                                        const float* __restrict__ mask, SeedRef seed, float p, int training,
-                                                       const float* __restrict__ w3, const float* __restrict__ dz, int C,
+                                                       const float* __restrict__ w3, const DzSrc dzs, int C,
                                                        float* __restrict__ S1, float* __restrict__ S2, float* __restrict__ dw3p,
                                                        float* __restrict__ dh2 = nullptr) {
     __shared__ float4 sm[SB_SLOTS][SB_LANES];
@@ -335,7 +357,7 @@ __global__ __launch_bounds__(SB) void k_head_bwd_stats(const float* __restrict__
         const float4 mu = ld4(mean + (size_t)g * C + c), rs = ld4(rstd + (size_t)g * C + c), w = ld4(w3 + c);
         for (int r = beg + slot; r < end; r += SB_SLOTS) {
             const int m = order ? order[r] : r;
-            const float d = dz[m];
+            const float d = dzs.get(m);
             float4 h = pre.load(m, c);
             float4 k = keep4(mask, seed, 2, m, c, C, p, training != 0);
             float4 y = make_float4((h.x - mu.x) * rs.x, (h.y - mu.y) * rs.y, (h.z - mu.z) * rs.z, (h.w - mu.w) * rs.w);
@@ -365,7 +387,7 @@ __global__ __launch_bounds__(SB) void k_head_bwd_stats(const float* __restrict__
         const float4 mu = ld4(mean + (size_t)g * C + c), rs = ld4(rstd + (size_t)g * C + c), w = ld4(w3 + c);
         for (int r = beg + slot; r < end; r += SB_SLOTS) {
             const int m = order ? order[r] : r;
-            const float d = dz[m];
+            const float d = dzs.get(m);
             const float4 h = pre.load(m, c);
             const float4 k = keep4(mask, seed, 2, m, c, C, p, training != 0);
             const float4 y = make_float4((h.x - mu.x) * rs.x, (h.y - mu.y) * rs.y, (h.z - mu.z) * rs.z, (h.w - mu.w) * rs.w);
@@ -586,6 +608,54 @@ __global__ __launch_bounds__(SB) void k_colsum(const float* __restrict__ x, int6
     }
 }
 
+// Tail of the head's backward for unsliced segments, ONE launch instead of four column-sum launches: blocks [0, ceil(C/64)):
+// dW3[c] = sum over the graphs of the per-graph partials of k_head_bwd_stats; last block: db3 = sum of k_dz's per-block sums.
+// 64 row slots x 16 lanes per block, eight rows in flight per slot; fixed summation order.
+constexpr int FIN_T = 1024, FIN_SLOTS = FIN_T / SB_LANES;
+__global__ __launch_bounds__(FIN_T) void k_head_bwd_finish(const float* __restrict__ dw3p, const float* __restrict__ dz_part, int64_t G, int ndz, int C,
+                                                           float* __restrict__ dW3, float* __restrict__ db3) {
+    __shared__ float4 sm[FIN_SLOTS][SB_LANES];
+    const int lane = threadIdx.x % SB_LANES, slot = threadIdx.x / SB_LANES;
+    const int ctiles = (C + 4 * SB_LANES - 1) / (4 * SB_LANES);
+    float4 acc = f4zero();
+    if ((int)blockIdx.x < ctiles) {
+        const int c = (blockIdx.x * SB_LANES + lane) * 4;
+        if (c < C) {
+            int64_t g = slot;
+            for (; g + 7 * FIN_SLOTS < G; g += 8 * FIN_SLOTS) {
+                float4 v[8];
+#pragma unroll
+                for (int j = 0; j < 8; ++j) v[j] = ld4(dw3p + (size_t)(g + j * FIN_SLOTS) * C + c);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) { acc.x += v[j].x; acc.y += v[j].y; acc.z += v[j].z; acc.w += v[j].w; }
+            }
+            for (; g < G; g += FIN_SLOTS) { const float4 v = ld4(dw3p + (size_t)g * C + c); acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w; }
+        }
+    } else {
+        for (int i = threadIdx.x; i < ndz; i += FIN_T) acc.x += dz_part[i];
+    }
+    sm[slot][lane] = acc;
+    __syncthreads();
+    if (slot == 0) {
+        float4 r = f4zero();
+        for (int s_ = 0; s_ < FIN_SLOTS; ++s_) { const float4 t = sm[s_][lane]; r.x += t.x; r.y += t.y; r.z += t.z; r.w += t.w; }
+        if ((int)blockIdx.x < ctiles) {
+            const int c = (blockIdx.x * SB_LANES + lane) * 4;
+            if (c < C) st4(dW3 + c, r);
+        } else {
+            sm[0][lane] = r;
+        }
+    }
+    if ((int)blockIdx.x >= ctiles) {
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            float r = 0.f;
+            for (int l = 0; l < SB_LANES; ++l) r += sm[0][l].x;
+            db3[0] = r;
+        }
+    }
+}
+
 __global__ void k_philox_noise(uint64_t seed, int64_t M, float* __restrict__ u) {
     const int64_t m = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (m < M) u[m] = philox_noise_u(seed, (int)m);
@@ -765,7 +835,7 @@ size_t gsat_attn_bwd_workspace_bytes(const gsat_attn_args* a) {
     const size_t M = (size_t)a->M, N = (size_t)a->N, G = (size_t)a->G, C1 = a->C1, C2 = a->C2;
     const size_t cmax = C1 > C2 ? C1 : C2;
     size_t b = 0;
-    b += align_up(M * 4, 256);                 // dz
+    b += align_up((M > G ? M : G) * 4, 256);   // dz (or its per-graph sums)
     b += align_up(M * C2 * 4, 256);            // dh2
     b += align_up(M * C1 * 4, 256);            // da1 -> dh1
     b += 2 * align_up(G * C1 * 4, 256);        // S1', S2'
@@ -799,7 +869,7 @@ int gsat_attn_bwd(const gsat_attn_args* a, const gsat_attn_grads* gr, void* stre
     GSAT_REQUIRE(!gr->datt || a->att, GSAT_ERR_ARG, "gsat_attn_bwd: datt given but att was not saved");
     if (a->edge_mode) GSAT_REQUIRE(gr->rowptr_src && gr->eid_by_src && gr->rowptr_dst && gr->eid_by_dst, GSAT_ERR_ARG, "gsat_attn_bwd: edge mode needs both CSRs");
     Arena ar(gr->workspace, gr->workspace_bytes);
-    float* dz = ar.take<float>(M);
+    float* dz = ar.take<float>(std::max<int64_t>(M, G));
     float* dh2 = ar.take<float>((size_t)M * C2);
     float* da1 = ar.take<float>((size_t)M * C1);
     float* S1p = ar.take<float>((size_t)G * C1);
@@ -832,17 +902,27 @@ int gsat_attn_bwd(const gsat_attn_args* a, const gsat_attn_grads* gr, void* stre
 
     // b1 and b2 sit in front of an InstanceNorm, which removes any per-channel constant of its segment: their
     // gradients are exactly zero (the reference's autograd returns ~1e-7 rounding noise of a cancelling sum).
-    k_dz<<<(unsigned)ceil_div(M, 256), 256, 0, stream>>>(gr->dlogits, gr->datt, a->att, M, dz, gr->db1, (int)C1, gr->db2, (int)C2);
-    GSAT_LAUNCH_CHECK();
-    if ((rc = colsum(stream, dz, M, 1, gr->db3, scratch))) return rc;
-    // ---- through the head and the second InstanceNorm ------------------------------------------
     const dim3 g2((unsigned)G, (unsigned)ceil_div(C2, 4 * SB_LANES), (unsigned)Z), g1((unsigned)G, (unsigned)ceil_div(C1, 4 * SB_LANES), (unsigned)Z);
+    // env GSAT_ATTN_BWD_MERGED=0: the round-2 sequence (two-stage column sums for db3 and dW3) also for unsliced segments (A/B switch)
+    const char* env_m = getenv("GSAT_ATTN_BWD_MERGED");
+    const bool merged = Z == 1 && G > 0 && !(env_m && atoi(env_m) == 0);
+    const unsigned dzb = (unsigned)ceil_div(M, 256);
+    float* dzpart = scratch;                         // [dzb] per-block sums of dz; `scratch` holds 256 * max(C1, C2) >= M / 256 floats for M < 2^24 C
+    const bool part_ok = (size_t)dzb <= (size_t)256 * std::max(C1, C2);
+    // b1 and b2 sit in front of an InstanceNorm, which removes any per-channel constant of its segment: their
+    // gradients are exactly zero (the reference's autograd returns ~1e-7 rounding noise of a cancelling sum).
+    k_dz<<<dzb, 256, 0, stream>>>(gr->dlogits, gr->datt, a->att, M, dz, gr->db1, (int)C1, gr->db2, (int)C2, (merged && part_ok) ? dzpart : nullptr);
+    GSAT_LAUNCH_CHECK();
+    if (!(merged && part_ok) && (rc = colsum(stream, dz, M, 1, gr->db3, scratch))) return rc;
+    // ---- through the head and the second InstanceNorm ------------------------------------------
     if (Z == 1)          // statistics and dh2 in one launch
         k_head_bwd_stats<true><<<g2, SB, 0, stream>>>(a->h2, a->b2, a->seg_ptr, a->seg_order, mean2, rstd2, a->mask2, SeedRef{a->seed, a->seed_dev}, a->p_drop,
-                                                      a->training, a->W3, dz, C2, S1, S2, dw3p, dh2);
+                                                      a->training, a->W3, DzSrc{dz, nullptr, nullptr, nullptr}, C2, S1, S2, dw3p, dh2);
     else
         k_head_bwd_stats<false><<<g2, SB, 0, stream>>>(a->h2, a->b2, a->seg_ptr, a->seg_order, mean2, rstd2, a->mask2, SeedRef{a->seed, a->seed_dev}, a->p_drop,
-                                                       a->training, a->W3, dz, C2, zp1, zp2, zp3);
+                                                       a->training, a->W3, DzSrc{dz, nullptr, nullptr, nullptr}, C2, zp1, zp2, zp3);
+    if (merged && part_ok)       // dW3 and db3 from the partials, one launch (instead of two two-stage column sums)
+        k_head_bwd_finish<<<(unsigned)ceil_div(C2, 4 * SB_LANES) + 1, FIN_T, 0, stream>>>(dw3p, dzpart, G, (int)dzb, C2, gr->dW3, gr->db3);
     if (Z > 1) {
         const unsigned cb = (unsigned)ceil_div(G * C2, 256);
         k_zcombine<<<cb, 256, 0, stream>>>(zp1, a->seg_ptr, (int)G, Z, C2, 1, S1);
@@ -850,7 +930,7 @@ int gsat_attn_bwd(const gsat_attn_args* a, const gsat_attn_grads* gr, void* stre
         k_zcombine<<<cb, 256, 0, stream>>>(zp3, a->seg_ptr, (int)G, Z, C2, 0, dw3p);
     }
     GSAT_LAUNCH_CHECK();
-    if ((rc = colsum(stream, dw3p, G, C2, gr->dW3, scratch))) return rc;
+    if (!(merged && part_ok) && (rc = colsum(stream, dw3p, G, C2, gr->dW3, scratch))) return rc;
     if (Z > 1) {
         k_dh2<<<ew_blocks(M * (C2 / 4)), 256, 0, stream>>>(a->h2, a->b2, a->row_seg, mean2, rstd2, a->mask2, SeedRef{a->seed, a->seed_dev}, a->p_drop, a->training,
                                                            a->W3, dz, S1, S2, M, C2, dh2);
