@@ -14,10 +14,10 @@ from .gsat import (GSAT, ExtractorMLP, concrete_sample, get_r, gumbel_sigmoid, i
                    lift_node_att_to_edge_att, symmetrise_edge_att)
 from .collate import PackedDataset, line_graph, line_graph_undirected
 from .dual_gsat import DualGSAT, f1_sparsity_loss
-from .graph_index import BatchIndex, clear_cache, get_index, set_sync_free
+from .graph_index import BatchIndex, clear_cache, get_index, set_strict, set_sync_free
 from .utils import process_data, reorder_like, set_seed
 
 __all__ = ["MLP", "BatchSequential", "Criterion", "InstanceNorm", "get_model", "get_preds", "GINConv", "GINEConv",
            "PNAConvSimple", "GIN", "PNA", "GSAT", "ExtractorMLP", "concrete_sample", "get_r", "gumbel_sigmoid",
-           "info_loss", "lift_node_att_to_edge_att", "symmetrise_edge_att", "BatchIndex", "get_index", "clear_cache", "set_sync_free",
+           "info_loss", "lift_node_att_to_edge_att", "symmetrise_edge_att", "BatchIndex", "get_index", "clear_cache", "set_sync_free", "set_strict",
            "process_data", "reorder_like", "set_seed", "DualGSAT", "f1_sparsity_loss", "LEConv", "SPMotifNet", "PackedDataset", "line_graph", "line_graph_undirected"]

@@ -52,6 +52,8 @@ SIGNATURES = {
     "gsat_bn_apply_fwd": (INT, [P, P, P, P, P, I64, I64, INT, P, F32, U64, P, P, P]),
     "gsat_bn_local_bwd_sums": (INT, [P, P, P, P, P, P, I64, I64, INT, F32, U64, P, P, P, P, P]),
     "gsat_bn_apply_bwd": (INT, [P, P, P, P, P, P, P, P, I64, P, I64, I64, INT, F32, U64, P, P, P, P]),
+    "gsat_relu_dropout_fwd": (INT, [P, I64, I64, F32, U64, P, P, P]),
+    "gsat_relu_dropout_bwd": (INT, [P, P, I64, I64, F32, P, P]),
     "gsat_colsum_workspace_floats": (SZ, [I64]),
     "gsat_colsum": (INT, [P, I64, I64, P, P, P]),
     "gsat_embsum_fwd": (INT, [P, P, INT, P, I64, I64, P, P]),

@@ -318,6 +318,51 @@ int gsat_bn_apply_fwd(const float* x, const float* gamma, const float* beta, con
     return GSAT_OK;
 }
 
+// ---- GIN layer tail: y = dropout_p(relu(x)) (src/models/gin.py:49-52), one launch forward, one backward (from y alone) ----------------
+constexpr int RELU_DROPOUT_STREAM = 5;
+__global__ void k_relu_dropout_fwd(const float* __restrict__ x, int64_t N, int C, float p, SeedRef seed, float* __restrict__ y) {
+    const int C4 = C >> 2;
+    const float s = p > 0.f ? 1.f / (1.f - p) : 1.f;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < N * C4; i += (int64_t)gridDim.x * blockDim.x) {
+        const float4 v = ld4(x + i * 4);
+        float4 o = make_float4(fmaxf(v.x, 0.f), fmaxf(v.y, 0.f), fmaxf(v.z, 0.f), fmaxf(v.w, 0.f));
+        if (p > 0.f) {
+            const float4 k = philox_keep4(seed.get(), RELU_DROPOUT_STREAM, (int)(i / C4), (int)(i % C4) * 4, p);
+            o = make_float4(o.x * k.x * s, o.y * k.y * s, o.z * k.z * s, o.w * k.w * s);
+        }
+        st4(y + i * 4, o);
+    }
+}
+// y > 0 <=> x > 0 and kept, so dx = dy / (1 - p) there and 0 elsewhere: no mask recomputation
+__global__ void k_relu_dropout_bwd(const float* __restrict__ y, const float* __restrict__ dy, int64_t n4, float s, float* __restrict__ dx) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (int64_t)gridDim.x * blockDim.x) {
+        const float4 v = ld4(y + i * 4), d = ld4(dy + i * 4);
+        st4(dx + i * 4, make_float4(v.x > 0.f ? d.x * s : 0.f, v.y > 0.f ? d.y * s : 0.f, v.z > 0.f ? d.z * s : 0.f, v.w > 0.f ? d.w * s : 0.f));
+    }
+}
+
+int gsat_relu_dropout_fwd(const float* x, int64_t N, int64_t C, float dropout_p, uint64_t seed, const uint64_t* seed_dev, float* y, void* stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    GSAT_REQUIRE(N >= 0 && C > 0 && C % 4 == 0 && N < (1ll << 31), GSAT_ERR_ARG, "gsat_relu_dropout_fwd: bad extents (C must be a multiple of 4)");
+    GSAT_REQUIRE(dropout_p >= 0.f && dropout_p < 1.f, GSAT_ERR_ARG, "gsat_relu_dropout_fwd: dropout_p must be in [0, 1)");
+    if (N == 0) return GSAT_OK;
+    GSAT_REQUIRE(x && y, GSAT_ERR_ARG, "gsat_relu_dropout_fwd: null pointer");
+    k_relu_dropout_fwd<<<ew_grid(N * (C / 4)), 256, 0, stream>>>(x, N, (int)C, dropout_p, SeedRef{seed, seed_dev}, y);
+    GSAT_LAUNCH_CHECK();
+    return GSAT_OK;
+}
+
+int gsat_relu_dropout_bwd(const float* y, const float* dy, int64_t N, int64_t C, float dropout_p, float* dx, void* stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    GSAT_REQUIRE(N >= 0 && C > 0 && C % 4 == 0 && N < (1ll << 31), GSAT_ERR_ARG, "gsat_relu_dropout_bwd: bad extents (C must be a multiple of 4)");
+    GSAT_REQUIRE(dropout_p >= 0.f && dropout_p < 1.f, GSAT_ERR_ARG, "gsat_relu_dropout_bwd: dropout_p must be in [0, 1)");
+    if (N == 0) return GSAT_OK;
+    GSAT_REQUIRE(y && dy && dx, GSAT_ERR_ARG, "gsat_relu_dropout_bwd: null pointer");
+    k_relu_dropout_bwd<<<ew_grid(N * (C / 4)), 256, 0, stream>>>(y, dy, N * (C / 4), dropout_p > 0.f ? 1.f / (1.f - dropout_p) : 1.f, dx);
+    GSAT_LAUNCH_CHECK();
+    return GSAT_OK;
+}
+
 int gsat_bn_local_bwd_sums(const float* x, const float* dy, const float* gamma, const float* beta, const float* mean, const float* rstd,
                            int64_t N, int64_t C, int relu, float dropout_p, uint64_t seed, const uint64_t* seed_dev, float* sum_dy,
                            float* sum_dy_xhat, float* workspace, void* stream_) {

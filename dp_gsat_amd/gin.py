@@ -7,7 +7,7 @@ import torch.nn.functional as F
 from .conv_layers import GINConv, GINEConv
 from .encoders import AtomEncoder, BatchNorm1d, BondEncoder, Linear
 from .graph_index import get_index
-from .ops import segment_pool
+from .ops import relu_dropout, segment_pool
 
 
 class _UpdateMLP(nn.Sequential):
@@ -61,8 +61,7 @@ class GIN(nn.Module):
             edge_attr = self.edge_encoder(edge_attr)
         for conv in self.convs:
             x = conv(x, edge_index, edge_attr=edge_attr, edge_atten=edge_atten, index=index)
-            x = self.relu(x)
-            x = F.dropout(x, p=self.dropout_p, training=self.training)
+            x = relu_dropout(x, self.dropout_p, self.training)          # relu + dropout, one launch each way (src/models/gin.py:50-51)
         return x
 
     def forward(self, x, edge_index, batch, edge_attr=None, edge_atten=None):

@@ -72,6 +72,22 @@ def _queue_status(index):
     index._status_event = slot[1]
 
 
+# Strict mode (debugging): the PNA ops normally learn about hub rows and bad ids through an asynchronous status copy, so a batch with
+# node ids outside [0, num_nodes) or an unsorted `batch` vector raises its ValueError one batch LATE on that path (the kernels clamp ids:
+# memory-safe, results of that batch meaningless).  set_strict(True) restores the reference's behaviour -- an immediate ValueError -- at
+# the price of one device->host read per batch in front of the first PNA launch.
+_STRICT = False
+
+
+def set_strict(flag: bool) -> None:
+    global _STRICT
+    _STRICT = bool(flag)
+
+
+def strict() -> bool:
+    return _STRICT
+
+
 def set_sync_free(flag: bool) -> None:
     global _SYNC_FREE
     _SYNC_FREE = bool(flag)
@@ -174,6 +190,8 @@ class BatchIndex:
     def long_rows_nowait(self):
         """`long_rows` without a host sync (see _HUBS_SEEN): exact when this batch's status is already on the host, else the chunk lists
         (whose launches exit early on a batch without hubs) iff hubs have been seen before in this process, else (None, None)."""
+        if _STRICT and not _SYNC_FREE and not self._checked and not torch.cuda.is_current_stream_capturing():
+            self._readback()                         # strict mode: bad ids / an unsorted batch vector raise HERE, before the first PNA launch
         if self._long is not None:
             known = self._long
         else:

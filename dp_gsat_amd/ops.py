@@ -578,6 +578,43 @@ class SyncBatchNormFn(torch.autograd.Function):
         return dx, dgamma, dbeta, None, None, None, None, None, dres, None, None, None, None
 
 
+class ReluDropout(torch.autograd.Function):
+    """dropout_p(relu(x)) in one launch, backward from the output alone (GIN layer tail, src/models/gin.py:49-52)."""
+
+    @staticmethod
+    def forward(ctx, x, p: float, seed: int, seed_dev):
+        x = _f32c(x)
+        N, C = x.shape
+        y = torch.empty_like(x)
+        call("gsat_relu_dropout_fwd", ptr(x), N, C, float(p), int(seed) & ((1 << 64) - 1), ptr(seed_dev), ptr(y), stream())
+        ctx.save_for_backward(y)
+        ctx.p = float(p)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        (y,) = ctx.saved_tensors
+        dy = _f32c(dy)
+        dx = torch.empty_like(y)
+        call("gsat_relu_dropout_bwd", ptr(y), ptr(dy), y.shape[0], y.shape[1], ctx.p, ptr(dx), stream())
+        return dx, None, None, None
+
+
+def relu_dropout(x, p: float, training: bool):
+    """F.dropout(relu(x), p, training) -- HIP for 2-D fp32 ROCm tensors with a width that is a multiple of 4, torch otherwise."""
+    p = float(p) if training else 0.0
+    if not (x.is_cuda and x.dim() == 2 and x.dtype == torch.float32 and x.shape[1] % 4 == 0):
+        return torch.nn.functional.dropout(torch.relu(x), p, training=True) if p > 0.0 else torch.relu(x)
+    seed, seed_dev = 0, None
+    if p > 0.0:
+        from .graph_index import sync_free
+        if sync_free():            # captured steps: the seed word lives on the device and is redrawn by a graph-safe RNG op
+            seed_dev = torch.empty(1, dtype=torch.int64, device=x.device).random_()
+        else:
+            seed = new_seed()
+    return ReluDropout.apply(x, p, seed, seed_dev)
+
+
 def colsum(x):
     """Deterministic column sum of a 2-D fp32 device tensor (bias gradients)."""
     from ._lib import load

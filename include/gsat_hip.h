@@ -442,6 +442,13 @@ int gsat_philox_noise(uint64_t seed, int64_t M, float* u, void* stream);
 int gsat_philox_keep_mask(uint64_t seed, int32_t layer, int64_t M, int64_t C, float p_drop, float* keep,
                           void* stream);
 
+/* GIN layer tail (src/models/gin.py:49-52: x = F.dropout(relu(conv(x)), p)): y = relu(x) * keep / (1 - p), keep drawn from the Philox
+ * stream 5 of `seed` keyed by (row, column) -- or from the device word `seed_dev` (captured steps).  The backward needs y alone:
+ * dx = dy / (1 - p) where y > 0, else 0.  C % 4 == 0. */
+int gsat_relu_dropout_fwd(const float* x, int64_t N, int64_t C, float dropout_p, uint64_t seed, const uint64_t* seed_dev, float* y,
+                          void* stream);
+int gsat_relu_dropout_bwd(const float* y, const float* dy, int64_t N, int64_t C, float dropout_p, float* dx, void* stream);
+
 /* ============================ samplers, lift, symmetrise, info loss ========================== */
 
 /*

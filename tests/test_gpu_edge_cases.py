@@ -364,6 +364,16 @@ def test_pna_path_reports_bad_ids_late_and_learns_hubs_without_a_sync(dev):
         for _ in range(3):                                                             # first use queues its own copy, the next ones harvest
             pna_aggregate(x, good, None, None, aggr, sc, avg)
             torch.cuda.synchronize()
+    # strict mode (debugging): the same bad batch raises at once, before the first PNA launch, as the reference's gathers would
+    G.clear_cache()
+    G.set_strict(True)
+    try:
+        bad2 = G.BatchIndex(torch.tensor([[0, 3, 1], [1, 0, 2]], device=dev), 3)
+        with pytest.raises(ValueError, match="outside"):
+            pna_aggregate(x, bad2, None, None, aggr, sc, avg)
+    finally:
+        G.set_strict(False)
+        G.clear_cache()
     # hubs: unknown -> plain kernels (correct), after the status has landed -> chunk lists
     hub = torch.stack([torch.arange(1, 400, device=dev), torch.zeros(399, dtype=torch.int64, device=dev)])
     ix = G.BatchIndex(hub.contiguous(), 400)

@@ -374,3 +374,21 @@ def test_training_trajectory_matches_oracle(dev, backbone, edge):
                               list(oclf.named_parameters()) + list(oext.named_parameters())):
         assert torch.isfinite(p).all(), k
         assert float((p.detach().cpu() - q.detach()).abs().max()) <= 5e-2 * max(1.0, float(q.detach().abs().max())), k
+
+
+@pytest.mark.parametrize("p", [0.0, 0.3])
+def test_relu_dropout_tail(dev, p):
+    """GIN layer tail (src/models/gin.py:50-51) in one launch: relu, Bernoulli(1 - p) keep mask scaled by 1 / (1 - p), backward from y."""
+    from dp_gsat_amd.ops import relu_dropout
+    x = torch.randn(3001, 64, device=dev).requires_grad_(True)
+    y = relu_dropout(x, p, True)
+    r = torch.relu(x.detach())
+    pos = r > 0
+    keep = (y > 0)[pos].float().mean().item()
+    assert abs(keep - (1 - p)) < 0.02
+    s = 1.0 / (1.0 - p)
+    assert torch.allclose(y[y > 0], (r * s)[y > 0], rtol=1e-6, atol=0) and bool((y[~pos] == 0).all())
+    go = torch.randn_like(y)
+    y.backward(go)
+    assert torch.allclose(x.grad, torch.where(y > 0, go * s, torch.zeros_like(go)), rtol=1e-6, atol=0)
+    assert torch.equal(relu_dropout(x.detach(), p, False), r)          # eval: plain relu
