@@ -17,6 +17,13 @@ struct FusedGeom {
     int lds_bytes;
 };
 
+// a tile of whole graphs: MLP rows [row0, row0 + nrows) of graphs [g0, g0 + ng), their nodes [node0, node0 + nnodes); flags & 1: one graph
+// larger than a tile ("big": walked in slabs)
+struct FTile { int row0, nrows, g0, ng, node0, nnodes, flags, pad; };
+size_t attn_plan_bytes(int64_t G);
+bool attn_plan_ok(int64_t G);
+int attn_plan_launch(hipStream_t stream, const int32_t* seg_ptr, const int32_t* node_ptr, int64_t G, int RM, int RX, FTile* tiles, int* counters);
+
 bool fused_geometry(int H, int C1, int C2, bool edge, FusedGeom* out);
 size_t fused_ws_bytes(const FusedGeom& g, int64_t G);
 bool attn_fused_eligible(const gsat_attn_args* a, FusedGeom* g);

@@ -29,7 +29,6 @@ constexpr int FT = 512;             // threads per workgroup: 8 waves = 4 column
 constexpr int F_RMAX = 128;         // rows of the largest tile
 constexpr float F_EPS = 1e-5f;
 
-struct FTile { int row0, nrows, g0, ng, node0, nnodes, flags, pad; };
 
 // ------------------------------------------------------------------------------------------------
 // geometry (host): LDS layout in floats.  node: [X | T | stats | meta]; edge: [X | U | T | stats | meta]; the layer-2 tile H2 overlays
@@ -122,11 +121,9 @@ __device__ __forceinline__ void plan_superblock(const int32_t* __restrict__ seg_
 constexpr int PLAN_T = 1024;
 constexpr int PLAN_MAX_SB = 4096;
 
-__global__ __launch_bounds__(PLAN_T) void k_attn_prep(const float* __restrict__ W1, const float* __restrict__ W2, FusedGeom g, int edge,
-                                                      const int32_t* __restrict__ seg_ptr, const int32_t* __restrict__ node_ptr, int G,
-                                                      FTile* __restrict__ tiles, int* __restrict__ counters, float4* __restrict__ Wp1,
-                                                      float4* __restrict__ Wp2) {
-    if (blockIdx.x == 0) {
+// Plans the tiles of a batch: called by ALL threads of ONE 1024-thread block.  counters[0] = tiles, [1] = 0 (queue head), [2] = big tiles.
+__device__ void plan_tiles_block(const int32_t* __restrict__ seg_ptr, const int32_t* __restrict__ node_ptr, int G, int RM, int RX,
+                                 FTile* __restrict__ tiles, int* __restrict__ counters) {
         __shared__ int sBig[PLAN_MAX_SB], sSmall[PLAN_MAX_SB], sBigCnt[PLAN_MAX_SB];
         __shared__ int sTot[2];
         const int nsb = (G + 63) / 64;
@@ -134,7 +131,7 @@ __global__ __launch_bounds__(PLAN_T) void k_attn_prep(const float* __restrict__ 
         FTile* const sparse = tiles + G + 1;                                  // [nsb * 64] scratch behind the compact list
         for (int sb = wave; sb < nsb; sb += PLAN_T / 64) {
             int nb, ns;
-            plan_superblock(seg_ptr, node_ptr, G, sb, g.RM, g.RX, &nb, &ns, sparse);
+            plan_superblock(seg_ptr, node_ptr, G, sb, RM, RX, &nb, &ns, sparse);
             if (lane == 0) { sBig[sb] = nb; sSmall[sb] = ns; }
         }
         __syncthreads();
@@ -164,6 +161,19 @@ __global__ __launch_bounds__(PLAN_T) void k_attn_prep(const float* __restrict__ 
         }
         if (threadIdx.x == 0) { counters[0] = sTot[0] + sTot[1]; counters[1] = 0; counters[2] = sTot[0]; }
         if (threadIdx.x >= 16 && threadIdx.x < 48) counters[threadIdx.x] = 0;       // diagnostic stamp words (GSAT_FUSED_STAMPS builds)
+}
+
+__global__ __launch_bounds__(PLAN_T) void k_attn_plan(const int32_t* __restrict__ seg_ptr, const int32_t* __restrict__ node_ptr, int G, int RM, int RX,
+                                                      FTile* __restrict__ tiles, int* __restrict__ counters) {
+    plan_tiles_block(seg_ptr, node_ptr, G, RM, RX, tiles, counters);
+}
+
+__global__ __launch_bounds__(PLAN_T) void k_attn_prep(const float* __restrict__ W1, const float* __restrict__ W2, FusedGeom g, int edge,
+                                                      const int32_t* __restrict__ seg_ptr, const int32_t* __restrict__ node_ptr, int G,
+                                                      FTile* __restrict__ tiles, int* __restrict__ counters, float4* __restrict__ Wp1,
+                                                      float4* __restrict__ Wp2) {
+    if (blockIdx.x == 0) {
+        plan_tiles_block(seg_ptr, node_ptr, G, g.RM, g.RX, tiles, counters);
         return;
     }
     const int64_t n1 = (int64_t)g.NCH * 4 * g.S1 * 64, n2 = (int64_t)g.NCH * g.NCB2 * g.S2 * 64;
@@ -743,6 +753,14 @@ static int launch_fused(hipStream_t stream, const FusedArgs& fa, int grid) {
         allowed = lds;
     }
     k_attn_fused_fwd<EDGE, NRB, NCB2W><<<grid, FT, lds, stream>>>(fa);
+    GSAT_LAUNCH_CHECK();
+    return GSAT_OK;
+}
+
+size_t attn_plan_bytes(int64_t G) { return align_up((size_t)(G + 1 + (G + 63) / 64 * 64) * sizeof(FTile), 256); }
+bool attn_plan_ok(int64_t G) { return G > 0 && G <= (int64_t)PLAN_MAX_SB * 64; }
+int attn_plan_launch(hipStream_t stream, const int32_t* seg_ptr, const int32_t* node_ptr, int64_t G, int RM, int RX, FTile* tiles, int* counters) {
+    k_attn_plan<<<1, PLAN_T, 0, stream>>>(seg_ptr, node_ptr, (int)G, RM, RX, tiles, counters);
     GSAT_LAUNCH_CHECK();
     return GSAT_OK;
 }
