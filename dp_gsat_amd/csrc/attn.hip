@@ -844,6 +844,7 @@ size_t gsat_attn_bwd_workspace_bytes(const gsat_attn_args* a) {
     { const size_t Z = seg_slices(a->M, a->G); if (Z > 1) b += 3 * align_up(G * Z * cmax * 4, 256); }   // sliced-segment partials
     if (a->edge_mode) b += 2 * align_up(N * C1 * 4, 256) + align_up(gsat_long_row_partial_floats(a->M, a->C1) * 4, 256);   // dP, dQ, hub partials
     b += align_up(attn_gemm_ws_floats(a) * 4, 256);          // split-K slabs of the weight-gradient GEMMs
+    if (attn_fused_bwd_eligible(a)) b += align_up(attn_fused_bwd_ws_bytes(a), 256);      // tiles, W2 fragment stream, per-workgroup partials
     return b + 1024;
 }
 
@@ -893,6 +894,9 @@ int gsat_attn_bwd(const gsat_attn_args* a, const gsat_attn_grads* gr, void* stre
     }
     GemmWs gws{nullptr, attn_gemm_ws_floats(a)};
     gws.ptr = ar.take<float>(gws.floats);
+    const bool fused_bwd = attn_fused_bwd_eligible(a) && seg_slices(M, G) == 1;
+    const size_t fws_bytes = fused_bwd ? attn_fused_bwd_ws_bytes(a) : 0;
+    char* fws = fused_bwd ? ar.take<char>(fws_bytes) : nullptr;
     GSAT_REQUIRE(ar.ok(), GSAT_ERR_WORKSPACE, "gsat_attn_bwd: workspace %zu < %zu", gr->workspace_bytes, ar.off);
     float* mean1 = a->stats;
     float* rstd1 = mean1 + (size_t)G * C1;
@@ -903,6 +907,9 @@ int gsat_attn_bwd(const gsat_attn_args* a, const gsat_attn_grads* gr, void* stre
     // b1 and b2 sit in front of an InstanceNorm, which removes any per-channel constant of its segment: their
     // gradients are exactly zero (the reference's autograd returns ~1e-7 rounding noise of a cancelling sum).
     const dim3 g2((unsigned)G, (unsigned)ceil_div(C2, 4 * SB_LANES), (unsigned)Z), g1((unsigned)G, (unsigned)ceil_div(C1, 4 * SB_LANES), (unsigned)Z);
+    if (fused_bwd) {          // one launch from (dlogits, datt) down to dh1 (in the da1 buffer), dW2 / dW3 / db3 included (attn_fused_bwd.hip)
+        if ((rc = attn_fused_bwd(stream, a, gr, da1, fws, fws_bytes))) return rc;
+    } else {
     // env GSAT_ATTN_BWD_MERGED=0: the round-2 sequence (two-stage column sums for db3 and dW3) also for unsliced segments (A/B switch)
     const char* env_m = getenv("GSAT_ATTN_BWD_MERGED");
     const bool merged = Z == 1 && G > 0 && !(env_m && atoi(env_m) == 0);
@@ -957,6 +964,7 @@ int gsat_attn_bwd(const gsat_attn_args* a, const gsat_attn_grads* gr, void* stre
         k_zcombine<<<cb, 256, 0, stream>>>(zp2, a->seg_ptr, (int)G, Z, C1, 1, S2p);
     }
     GSAT_LAUNCH_CHECK();
+    }       // staged path
     if (a->edge_mode) {
         if (Z > 1) {
             PreAct<true> pre{a->P, a->Q, a->b1, a->src, a->dst, C1};

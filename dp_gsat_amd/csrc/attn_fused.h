@@ -29,6 +29,11 @@ size_t fused_ws_bytes(const FusedGeom& g, int64_t G);
 bool attn_fused_eligible(const gsat_attn_args* a, FusedGeom* g);
 int attn_fused_fwd(hipStream_t stream, const gsat_attn_args* a, const FusedGeom& g);
 
+// fused backward (attn_fused_bwd.hip): (dlogits, datt) -> dh1 [M, C1], dW2, dW3, db3 (db1 = db2 = 0) in one launch + one reduction
+bool attn_fused_bwd_eligible(const gsat_attn_args* a);
+size_t attn_fused_bwd_ws_bytes(const gsat_attn_args* a);
+int attn_fused_bwd(hipStream_t stream, const gsat_attn_args* a, const gsat_attn_grads* gr, float* dh1, void* ws, size_t ws_bytes);
+
 #ifdef __HIPCC__
 // dropout keep-mask of 4 consecutive channels: explicit tensor, or Philox keyed by (seed, layer, row, column) -- the same draw as
 // gsat_philox_keep_mask and the unfused kernels of attn.hip

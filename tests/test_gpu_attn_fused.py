@@ -201,3 +201,76 @@ def test_fused_extractor_module_vs_oracle_with_big_graph(dev, edge_mode, monkeyp
     close(ed.grad, r32["demb"], ref64=r64["demb"], what="demb")
     for k, p in ext.named_parameters():
         close(p.grad, r32[k], ref64=r64[k], what=k)
+
+
+def _fwd_bwd(dev, emb, params, ei, batch, G_, edge_mode, masks, u, dlogits, datt, fused_bwd, monkeypatch, p=0.5, training=True):
+    """gsat_attn_fwd (staged) + gsat_attn_bwd through the C ABI; returns the gradients."""
+    from dp_gsat_amd import _lib
+    from dp_gsat_amd._lib import AttnGrads, call, ptr, stream
+    from dp_gsat_amd.graph_index import BatchIndex
+    from dp_gsat_amd.ops import _attn_args
+    monkeypatch.setenv("GSAT_ATTN_BWD_FUSED", "1" if fused_bwd else "0")
+    index = BatchIndex(ei.to(dev), emb.shape[0])
+    seg = index.graphs(batch.to(dev), G_)
+    N, H = emb.shape
+    C1, C2 = params[0].shape[0], params[2].shape[0]
+    M = index.E if edge_mode else N
+    f32 = torch.float32
+    mk = lambda *s: torch.empty(*s, dtype=f32, device=dev)
+    bufs = (mk(N, C1), mk(N, C1) if edge_mode else None, mk(M, C1), mk(M, C2), mk(max(G_, 1) * (2 * C1 + 2 * C2)), mk(M, 1), mk(M, 1))
+    m1, m2 = masks if masks is not None else (None, None)
+    args = _attn_args(emb, params, index, seg, edge_mode, training, p, 7, m1, m2, u, bufs, None, u is None and training)
+    args.fused = -1
+    n = int(_lib.load().gsat_attn_fwd_workspace_bytes(ctypes.byref(args)))
+    ws = torch.empty(max(n, 16), dtype=torch.uint8, device=dev)
+    args.fwd_workspace, args.fwd_workspace_bytes = ptr(ws), n
+    call("gsat_attn_fwd", ctypes.byref(args), stream())
+    g = AttnGrads()
+    g.dlogits, g.datt = ptr(dlogits), ptr(datt)
+    if edge_mode:
+        g.rowptr_src, g.eid_by_src = ptr(index.rowptr_src), ptr(index.eid_by_src)
+        g.rowptr_dst, g.eid_by_dst = ptr(index.rowptr_dst), ptr(index.eid_by_dst)
+        g.chunk_ptr_dst, g.chunk_ptr_src = (ptr(t) for t in index.long_rows)
+    demb = torch.full_like(emb, float("nan"))
+    grads = [torch.full_like(t, float("nan")) for t in params]
+    g.demb = ptr(demb)
+    g.dW1, g.db1, g.dW2, g.db2, g.dW3, g.db3 = (ptr(t) for t in grads)
+    nb = int(_lib.load().gsat_attn_bwd_workspace_bytes(ctypes.byref(args)))
+    wsb = torch.empty(nb, dtype=torch.uint8, device=dev)
+    g.workspace, g.workspace_bytes = ptr(wsb), nb
+    call("gsat_attn_bwd", ctypes.byref(args), ctypes.byref(g), stream())
+    torch.cuda.synchronize()
+    return dict(demb=demb, dW1=grads[0], db1=grads[1], dW2=grads[2], db2=grads[3], dW3=grads[4], db3=grads[5])
+
+
+BWD_CASES = {
+    "molecules": [25, 31, 12, 40, 96, 7, 18, 22, 64, 33, 29, 3, 2, 51, 17, 128, 1, 0, 45],
+    "tiny": [0, 1, 1, 2, 1, 3, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 0, 5, 0],
+    "big_graphs": [20, 165, 30, 417, 9, 129, 128, 40],
+}
+
+
+@pytest.mark.parametrize("case", list(BWD_CASES))
+@pytest.mark.parametrize("H", [16, 64, 80, 128])
+@pytest.mark.parametrize("edge_mode", [False, True])
+@pytest.mark.parametrize("training", [True, False])
+def test_fused_backward_equals_staged_backward(dev, case, H, edge_mode, training, monkeypatch):
+    sizes = BWD_CASES[case]
+    ei, batch, N = _sized_batch(sizes, seed=H + 1)
+    ei = shuffle_edges(ei, 3)
+    if edge_mode and (ei.shape[1] == 0 or 4 * H > 512):
+        pytest.skip("no edges / layer-1 width beyond the fused backward")
+    G_ = len(sizes)
+    g = torch.Generator().manual_seed(5)
+    emb = torch.randn(N, H, generator=g).to(dev)
+    params = _params(H, edge_mode, dev, 11)
+    M = ei.shape[1] if edge_mode else N
+    C1, C2 = params[0].shape[0], params[2].shape[0]
+    masks = ((torch.rand(M, C1, generator=g) > 0.5).float().to(dev), (torch.rand(M, C2, generator=g) > 0.5).float().to(dev)) if training else None
+    u = torch.rand(M, generator=g).clamp_(1e-6, 1 - 1e-6).to(dev) if training else None
+    dl, da = torch.randn(M, generator=g).to(dev), torch.randn(M, generator=g).to(dev)
+    a = _fwd_bwd(dev, emb, params, ei, batch, G_, edge_mode, masks, u, dl, da, True, monkeypatch, training=training)
+    b = _fwd_bwd(dev, emb, params, ei, batch, G_, edge_mode, masks, u, dl, da, False, monkeypatch, training=training)
+    for k in a:
+        assert not torch.isnan(a[k]).any(), f"{k}: unwritten entries"
+        close(a[k], b[k], 1e-4, what=k)          # both paths run the split-bf16 policy; orders of summation differ
