@@ -33,7 +33,7 @@ constexpr int B_RM = 128;                 // MLP rows per tile
 constexpr int B_CH = 64;                  // layer-1 channels per chunk
 constexpr int B_SBA = B_CH * 2 + 16;      // bytes per row of an a1 plane (128 B of bf16 + 16 B pad)
 constexpr int B_LDT = B_CH + 4;           // floats per row of the da1 tile
-constexpr int B_RC = 32;                  // rows of a column kept in registers
+constexpr int B_CB = 16;                  // rows of a column in flight per batch
 
 struct BwdGeom {
     int C1, C2, C2p, NCH, S2b, SBH;       // S2b = C2p / 16 k-steps of the da1 product; SBH = bytes per row of a dh2 plane
@@ -108,7 +108,7 @@ __global__ void k_attn_bwd_pack(const float* __restrict__ W2, int C1, int C2, in
     }
 }
 
-template <bool EDGE, int NCHT>
+template <bool EDGE, int NCHT, bool BIG>
 __global__ __launch_bounds__(BT, 2) void k_attn_fused_bwd(const BwdArgs A) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const BwdGeom& g = A.g;
@@ -163,14 +163,17 @@ __global__ __launch_bounds__(BT, 2) void k_attn_fused_bwd(const BwdArgs A) {
             const unsigned char* ah = D2hi + (rb * 32 + (lane & 31)) * SBH + (lane >> 5) * 16;
             const unsigned char* al = ah + B_RM * SBH;
             const uint4* bp = A.Wq2 + ((size_t)((kc * 2 + cb) * g.S2b) * 2) * 64 + lane;
+            uint4 wh = bp[0], wl = bp[64];
             for (int s = 0; s < g.S2b; ++s) {
+                const int sn = min(s + 1, g.S2b - 1);                          // next step's weights fly under this step's MFMAs
+                const uint4 nh = bp[(size_t)sn * 128], nl = bp[(size_t)sn * 128 + 64];
                 const bf16x8 xh = *reinterpret_cast<const bf16x8*>(ah + s * 32);
                 const bf16x8 xl = *reinterpret_cast<const bf16x8*>(al + s * 32);
-                const uint4 wh = bp[(size_t)s * 128], wl = bp[(size_t)s * 128 + 64];
                 const bf16x8 bh = __builtin_bit_cast(bf16x8, wh), bl = __builtin_bit_cast(bf16x8, wl);
                 acc = GSAT_MFMA_BF16(xl, bh, acc);
                 acc = GSAT_MFMA_BF16(xh, bl, acc);
                 acc = GSAT_MFMA_BF16(xh, bh, acc);
+                wh = nh; wl = nl;
             }
             float* const o = T + (rb * 32 + 4 * (lane >> 5)) * B_LDT + cb * 32 + (lane & 31);
 #pragma unroll
@@ -196,9 +199,19 @@ __global__ __launch_bounds__(BT, 2) void k_attn_fused_bwd(const BwdArgs A) {
         return acc;
     };
 
-    for (int t = blockIdx.x; t < ntiles; t += gridDim.x) {
+#ifdef GSAT_FUSED_STAMPS
+    long long stamp[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    long long tlast = __builtin_amdgcn_s_memtime();
+#define BSTAMP(i) do { if (tid == 0) { const long long n_ = __builtin_amdgcn_s_memtime(); stamp[i] += n_ - tlast; tlast = n_; } } while (0)
+#else
+#define BSTAMP(i)
+#endif
+    const int nbig = A.counters[2];
+    if ((int)blockIdx.x >= (BIG ? nbig : ntiles - nbig)) return;      // no tile for this workgroup: no partial either (the reduction counts slabs the same way)
+    const int slab = (BIG ? (int)gridDim.x : 0) + (int)blockIdx.x;
+    for (int t = (BIG ? 0 : nbig) + blockIdx.x; t < (BIG ? nbig : ntiles); t += gridDim.x) {
         const FTile tl = A.tiles[t];
-        if (tl.flags & 1) {
+        if (BIG) {
             // ======================= one graph larger than a tile: 128-row slabs, statistics over ALL its rows first =======================
             const int nR = tl.nrows, gi = tl.g0;
             const float inv_n = 1.f / (float)max(nR, 1);
@@ -324,6 +337,8 @@ __global__ __launch_bounds__(BT, 2) void k_attn_fused_bwd(const BwdArgs A) {
             }
             continue;
         }
+
+        // ======================================= whole graphs in one tile =======================================
         const int nr = tl.nrows, nr16 = (nr + 15) & ~15;
         bwd_barrier();
         // ---- P0: tile meta, dz, keep bits of layer 2 -------------------------------------------------------------------------
@@ -338,80 +353,73 @@ __global__ __launch_bounds__(BT, 2) void k_attn_fused_bwd(const BwdArgs A) {
         for (int i = tid; i < nr * FB2; i += BT) {
             const int r = i / FB2, q = i - r * FB2;
             unsigned bits = 15u;
-            if (drop) {
+            if (drop && 4 * q < C2) {
                 const int gr = tl.row0 + r;
                 const int m = EDGE ? (A.order ? A.order[gr] : gr) : gr;
-                if (4 * q < C2) {
-                    const float4 k = keep4f(A.mask2, A.seed, 2, m, 4 * q, C2, A.p, true);
-                    bits = (k.x != 0.f ? 1u : 0u) | (k.y != 0.f ? 2u : 0u) | (k.z != 0.f ? 4u : 0u) | (k.w != 0.f ? 8u : 0u);
-                }
+                const float4 k = keep4f(A.mask2, A.seed, 2, m, 4 * q, C2, A.p, true);
+                bits = (k.x != 0.f ? 1u : 0u) | (k.y != 0.f ? 2u : 0u) | (k.z != 0.f ? 4u : 0u) | (k.w != 0.f ? 8u : 0u);
             }
             F2[i] = (unsigned char)bits;
         }
         bwd_barrier();
+        BSTAMP(0);
         // ---- P1: layer-2 column pass: S1, S2, dW3 / db3 partials, dh2 -> bf16 planes ---------------------------------------------------
+        // A column is walked in batches of CB rows, twice (sums, then gradients): every load of a batch is unconditional (row clamped
+        // into the graph) and in flight together, nothing but the two sums lives across batches, and the clamped duplicates of the last
+        // row rewrite identical values.
         if (slot2 < nslot2) {
             unsigned short* const ph = reinterpret_cast<unsigned short*>(D2hi) + cc2;
             unsigned short* const pl = reinterpret_cast<unsigned short*>(D2lo) + cc2;
             const int SH = SBH >> 1;                                   // plane row stride in bf16 units
             if (cc2 < C2) {
                 const float bias = A.b2[cc2], w = A.w3[cc2];
+                const int sh2 = cc2 & 3;
                 for (int gl = slot2; gl < tl.ng; gl += nslot2) {
                     const int b = sGptr[gl], e = sGptr[gl + 1], n = e - b;
                     if (n <= 0) continue;
                     const float inv_n = 1.f / (float)n;
                     const float mu = mean2[(size_t)(tl.g0 + gl) * C2 + cc2], rs = rstd2[(size_t)(tl.g0 + gl) * C2 + cc2];
-                    float y[B_RC];
+                    float yv[B_CB], dy[B_CB], dzv[B_CB];
+                    auto batch = [&](int r0) {
+                        unsigned kb[B_CB];
 #pragma unroll
-                    for (int j = 0; j < B_RC; ++j) {
-                        const int r = b + min(j, n - 1);
-                        const int m = EDGE ? sRowId[r] : tl.row0 + r;
-                        y[j] = A.h2[(size_t)m * C2 + cc2];
-                    }
+                        for (int j = 0; j < B_CB; ++j) {
+                            const int r = min(r0 + j, e - 1);
+                            const int m = EDGE ? sRowId[r] : tl.row0 + r;
+                            yv[j] = A.h2[(size_t)m * C2 + cc2];
+                            kb[j] = F2[r * FB2 + (cc2 >> 2)];
+                            dzv[j] = sDz[r];
+                        }
+#pragma unroll
+                        for (int j = 0; j < B_CB; ++j) {
+                            yv[j] = ((yv[j] + bias) - mu) * rs;
+                            const bool on = (((kb[j] >> sh2) & 1u) != 0u) & (yv[j] > 0.f);
+                            dy[j] = on ? dzv[j] * w * sc : 0.f;
+                        }
+                    };
                     float s1 = 0.f, s2 = 0.f;
+                    for (int r0 = b; r0 < e; r0 += B_CB) {
+                        batch(r0);
 #pragma unroll
-                    for (int j = 0; j < B_RC; ++j) {
-                        const int r = b + min(j, n - 1);
-                        y[j] = ((y[j] + bias) - mu) * rs;
-                        const bool on = j < n && ((F2[r * FB2 + (cc2 >> 2)] >> (cc2 & 3)) & 1) && y[j] > 0.f;
-                        const float d = sDz[r];
-                        const float dy = on ? d * w * sc : 0.f;
-                        s1 += dy; s2 = fmaf(dy, y[j], s2);
-                        dw3acc += on ? d * (y[j] * sc) : 0.f;
-                        if (cc2 == 0 && j < n) db3acc += d;
-                    }
-                    for (int r = b + B_RC; r < e; ++r) {             // rows beyond the register cache (graphs of > 32 rows)
-                        const int m = EDGE ? sRowId[r] : tl.row0 + r;
-                        const float yy = ((A.h2[(size_t)m * C2 + cc2] + bias) - mu) * rs;
-                        const bool on = ((F2[r * FB2 + (cc2 >> 2)] >> (cc2 & 3)) & 1) && yy > 0.f;
-                        const float d = sDz[r];
-                        const float dy = on ? d * w * sc : 0.f;
-                        s1 += dy; s2 = fmaf(dy, yy, s2);
-                        dw3acc += on ? d * (yy * sc) : 0.f;
-                        if (cc2 == 0) db3acc += d;
+                        for (int j = 0; j < B_CB; ++j) {
+                            const bool live = r0 + j < e;
+                            s1 += live ? dy[j] : 0.f;
+                            s2 += live ? dy[j] * yv[j] : 0.f;
+                            dw3acc += (live & (dy[j] != 0.f)) ? dzv[j] * (yv[j] * sc) : 0.f;
+                            db3acc += (live & (cc2 == 0)) ? dzv[j] : 0.f;
+                        }
                     }
                     const float S1 = s1 * inv_n, S2 = s2 * inv_n;
+                    for (int r0 = b; r0 < e; r0 += B_CB) {
+                        batch(r0);
 #pragma unroll
-                    for (int j = 0; j < B_RC; ++j) {
-                        if (j < n) {
-                            const int r = b + j;
-                            const bool on = ((F2[r * FB2 + (cc2 >> 2)] >> (cc2 & 3)) & 1) && y[j] > 0.f;
-                            const float dy = on ? sDz[r] * w * sc : 0.f;
-                            const float dh = rs * (dy - S1 - y[j] * S2);
+                        for (int j = 0; j < B_CB; ++j) {
+                            const int r = min(r0 + j, e - 1);
+                            const float dh = rs * (dy[j] - S1 - yv[j] * S2);
                             const unsigned short hb = bf16_bits(dh);
                             ph[r * SH] = hb;
                             pl[r * SH] = bf16_bits(dh - bf16_val(hb));
                         }
-                    }
-                    for (int r = b + B_RC; r < e; ++r) {
-                        const int m = EDGE ? sRowId[r] : tl.row0 + r;
-                        const float yy = ((A.h2[(size_t)m * C2 + cc2] + bias) - mu) * rs;
-                        const bool on = ((F2[r * FB2 + (cc2 >> 2)] >> (cc2 & 3)) & 1) && yy > 0.f;
-                        const float dy = on ? sDz[r] * w * sc : 0.f;
-                        const float dh = rs * (dy - S1 - yy * S2);
-                        const unsigned short hb = bf16_bits(dh);
-                        ph[r * SH] = hb;
-                        pl[r * SH] = bf16_bits(dh - bf16_val(hb));
                     }
                 }
                 for (int r = nr + slot2; r < nr16; r += nslot2) { ph[r * SH] = 0; pl[r * SH] = 0; }     // k-padding rows of the dW2 product
@@ -420,25 +428,25 @@ __global__ __launch_bounds__(BT, 2) void k_attn_fused_bwd(const BwdArgs A) {
             }
         }
         bwd_barrier();
+        BSTAMP(1);
         // ---- chunks of 64 layer-1 channels ---------------------------------------------------------------------------------------
 #pragma unroll
         for (int kc = 0; kc < NCHT; ++kc) {
-            if (kc * B_CH < C1) {          // (no `break`: the loop must unroll completely so that accW[kc] stays in registers)
+            if (kc * B_CH < C1) {          // (no `break`: accW[kc] keeps a compile-time index)
             // P2: da1 chunk = dh2 x W2[:, chunk] ; keep bits of the chunk
-            {
-                mfma_da1(kc, nr);
-                for (int i = tid; i < nr * 16; i += BT) {
-                    const int r = i >> 4, q = i & 15;
-                    unsigned bits = 15u;
-                    const int col = kc * B_CH + 4 * q;
-                    if (drop && col < C1) {
-                        const float4 k = keep4f(A.mask1, A.seed, 1, sRowId[r], col, C1, A.p, true);
-                        bits = (k.x != 0.f ? 1u : 0u) | (k.y != 0.f ? 2u : 0u) | (k.z != 0.f ? 4u : 0u) | (k.w != 0.f ? 8u : 0u);
-                    }
-                    F1[i] = (unsigned char)bits;
+            mfma_da1(kc, nr);
+            for (int i = tid; i < nr * 16; i += BT) {
+                const int r = i >> 4, q = i & 15;
+                unsigned bits = 15u;
+                const int col = kc * B_CH + 4 * q;
+                if (drop && col < C1) {
+                    const float4 k = keep4f(A.mask1, A.seed, 1, sRowId[r], col, C1, A.p, true);
+                    bits = (k.x != 0.f ? 1u : 0u) | (k.y != 0.f ? 2u : 0u) | (k.z != 0.f ? 4u : 0u) | (k.w != 0.f ? 8u : 0u);
                 }
+                F1[i] = (unsigned char)bits;
             }
             bwd_barrier();
+            BSTAMP(2);
             // P3: layer-1 column pass: y1 from P (| P[src] + Q[dst]), a1 -> planes, S1', S2', dh1 -> global
             {
                 const int col = kc * B_CH + cc1;
@@ -447,64 +455,62 @@ __global__ __launch_bounds__(BT, 2) void k_attn_fused_bwd(const BwdArgs A) {
                 constexpr int SH = B_SBA >> 1;
                 if (col < C1) {
                     const float bias = A.b1[col];
+                    const int sh1 = cc1 & 3;
                     for (int gl = slot1; gl < tl.ng; gl += BT / 64) {
                         const int b = sGptr[gl], e = sGptr[gl + 1], n = e - b;
                         if (n <= 0) continue;
                         const float inv_n = 1.f / (float)n;
                         const float mu = mean1[(size_t)(tl.g0 + gl) * C1 + col], rs = rstd1[(size_t)(tl.g0 + gl) * C1 + col];
-                        float y[B_RC];
-#pragma unroll
-                        for (int j = 0; j < B_RC; ++j) {
-                            const int r = b + min(j, n - 1);
-                            if (EDGE) y[j] = A.P[(size_t)sSrc[r] * C1 + col] + A.Q[(size_t)sDst[r] * C1 + col];
-                            else y[j] = A.P[(size_t)(tl.row0 + r) * C1 + col];
-                        }
+                        float yv[B_CB], dy[B_CB];
                         float s1 = 0.f, s2 = 0.f;
+                        for (int r0 = b; r0 < e; r0 += B_CB) {
+                            unsigned kb[B_CB];
+                            float q[B_CB];
 #pragma unroll
-                        for (int j = 0; j < B_RC; ++j) {
-                            const int r = b + min(j, n - 1);
-                            y[j] = ((y[j] + bias) - mu) * rs;
-                            const bool on = j < n && ((F1[r * 16 + (cc1 >> 2)] >> (cc1 & 3)) & 1) && y[j] > 0.f;
-                            const float dy = on ? T[r * B_LDT + cc1] * sc : 0.f;
-                            s1 += dy; s2 = fmaf(dy, y[j], s2);
-                        }
-                        for (int r = b + B_RC; r < e; ++r) {
-                            float h;
-                            if (EDGE) h = A.P[(size_t)sSrc[r] * C1 + col] + A.Q[(size_t)sDst[r] * C1 + col];
-                            else h = A.P[(size_t)(tl.row0 + r) * C1 + col];
-                            const float yy = ((h + bias) - mu) * rs;
-                            const bool on = ((F1[r * 16 + (cc1 >> 2)] >> (cc1 & 3)) & 1) && yy > 0.f;
-                            const float dy = on ? T[r * B_LDT + cc1] * sc : 0.f;
-                            s1 += dy; s2 = fmaf(dy, yy, s2);
+                            for (int j = 0; j < B_CB; ++j) {
+                                const int r = min(r0 + j, e - 1);
+                                if (EDGE) { yv[j] = A.P[(size_t)sSrc[r] * C1 + col]; q[j] = A.Q[(size_t)sDst[r] * C1 + col]; }
+                                else { yv[j] = A.P[(size_t)(tl.row0 + r) * C1 + col]; q[j] = 0.f; }
+                                kb[j] = F1[r * 16 + (cc1 >> 2)];
+                                dy[j] = T[r * B_LDT + cc1];
+                            }
+#pragma unroll
+                            for (int j = 0; j < B_CB; ++j) {
+                                if (EDGE) yv[j] += q[j];
+                                yv[j] = ((yv[j] + bias) - mu) * rs;
+                                const bool on = (((kb[j] >> sh1) & 1u) != 0u) & (yv[j] > 0.f);
+                                const float d = on ? dy[j] * sc : 0.f;
+                                const bool live = r0 + j < e;
+                                s1 += live ? d : 0.f;
+                                s2 += live ? d * yv[j] : 0.f;
+                            }
                         }
                         const float S1 = s1 * inv_n, S2 = s2 * inv_n;
+                        for (int r0 = b; r0 < e; r0 += B_CB) {
+                            unsigned kb[B_CB];
+                            float q[B_CB];
 #pragma unroll
-                        for (int j = 0; j < B_RC; ++j) {
-                            if (j < n) {
-                                const int r = b + j;
-                                const bool on = ((F1[r * 16 + (cc1 >> 2)] >> (cc1 & 3)) & 1) && y[j] > 0.f;
-                                const float dy = on ? T[r * B_LDT + cc1] * sc : 0.f;
-                                const float a1 = on ? y[j] * sc : 0.f;
+                            for (int j = 0; j < B_CB; ++j) {
+                                const int r = min(r0 + j, e - 1);
+                                if (EDGE) { yv[j] = A.P[(size_t)sSrc[r] * C1 + col]; q[j] = A.Q[(size_t)sDst[r] * C1 + col]; }
+                                else { yv[j] = A.P[(size_t)(tl.row0 + r) * C1 + col]; q[j] = 0.f; }
+                                kb[j] = F1[r * 16 + (cc1 >> 2)];
+                                dy[j] = T[r * B_LDT + cc1];
+                            }
+#pragma unroll
+                            for (int j = 0; j < B_CB; ++j) {
+                                const int r = min(r0 + j, e - 1);
+                                if (EDGE) yv[j] += q[j];
+                                yv[j] = ((yv[j] + bias) - mu) * rs;
+                                const bool on = (((kb[j] >> sh1) & 1u) != 0u) & (yv[j] > 0.f);
+                                const float d = on ? dy[j] * sc : 0.f;
+                                const float a1 = on ? yv[j] * sc : 0.f;
                                 const unsigned short hb = bf16_bits(a1);
                                 ph[r * SH] = hb;
                                 pl[r * SH] = bf16_bits(a1 - bf16_val(hb));
                                 const int m = EDGE ? sRowId[r] : tl.row0 + r;
-                                A.dh1[(size_t)m * C1 + col] = rs * (dy - S1 - y[j] * S2);
+                                A.dh1[(size_t)m * C1 + col] = rs * (d - S1 - yv[j] * S2);
                             }
-                        }
-                        for (int r = b + B_RC; r < e; ++r) {
-                            float h;
-                            if (EDGE) h = A.P[(size_t)sSrc[r] * C1 + col] + A.Q[(size_t)sDst[r] * C1 + col];
-                            else h = A.P[(size_t)(tl.row0 + r) * C1 + col];
-                            const float yy = ((h + bias) - mu) * rs;
-                            const bool on = ((F1[r * 16 + (cc1 >> 2)] >> (cc1 & 3)) & 1) && yy > 0.f;
-                            const float dy = on ? T[r * B_LDT + cc1] * sc : 0.f;
-                            const float a1 = on ? yy * sc : 0.f;
-                            const unsigned short hb = bf16_bits(a1);
-                            ph[r * SH] = hb;
-                            pl[r * SH] = bf16_bits(a1 - bf16_val(hb));
-                            const int m = EDGE ? sRowId[r] : tl.row0 + r;
-                            A.dh1[(size_t)m * C1 + col] = rs * (dy - S1 - yy * S2);
                         }
                     }
                     for (int r = nr + slot1; r < nr16; r += BT / 64) { ph[r * SH] = 0; pl[r * SH] = 0; }
@@ -513,16 +519,18 @@ __global__ __launch_bounds__(BT, 2) void k_attn_fused_bwd(const BwdArgs A) {
                 }
             }
             bwd_barrier();
+            BSTAMP(3);
             // P4: dW2[:, chunk] += dh2^T a1 (wave: c2 block wave >> 1, chunk column block wave & 1); k = tile rows, zero-padded to 16
             accW[kc] = mfma_dw2(accW[kc], nr16);
             bwd_barrier();
+            BSTAMP(4);
             }
         }
     }
     // ---- this workgroup's partials: dW2 [C2p, C1pad] from the accumulators, dW3 [C2p] and db3 over the column threads' slots ----------
     {
         const int ib = wave >> 1, jb = wave & 1;
-        float* const pw = A.partW2 + (size_t)blockIdx.x * C2p * g.C1pad;
+        float* const pw = A.partW2 + (size_t)slab * C2p * g.C1pad;
         if (ib * 32 < C2p) {
 #pragma unroll
             for (int kc = 0; kc < NCHT; ++kc) {
@@ -543,21 +551,32 @@ __global__ __launch_bounds__(BT, 2) void k_attn_fused_bwd(const BwdArgs A) {
         if (tid < C2p) {
             float s = 0.f;
             for (int k = 0; k < nslot2; ++k) s += red[k * C2p + tid];
-            A.partW3[(size_t)blockIdx.x * C2p + tid] = s;
+            A.partW3[(size_t)slab * C2p + tid] = s;
         }
         if (tid == 0) {
             float s = 0.f;
             for (int k = 0; k < nslot2; ++k) s += red[nslot2 * C2p + k];
-            A.partB3[blockIdx.x] = s;
+            A.partB3[slab] = s;
         }
     }
+#ifdef GSAT_FUSED_STAMPS
+    BSTAMP(5);
+    if (tid == 0) {
+        unsigned long long* o = reinterpret_cast<unsigned long long*>(const_cast<int*>(A.counters) + 16);
+        for (int i = 0; i < 8; ++i) atomicAdd(o + i, (unsigned long long)stamp[i]);
+        atomicAdd(o + 14, 1ull);
+    }
+#endif
 }
 
 // dW2 / dW3 / db3 = sums of the per-workgroup partials in workgroup order (eight partial sums in flight: fixed order, bitwise
 // reproducible); the two bias gradients that are identically zero (b1, b2 sit in front of an InstanceNorm) are cleared here too.
 __global__ void k_attn_bwd_reduce(const float* __restrict__ partW2, const float* __restrict__ partW3, const float* __restrict__ partB3, int nwg,
-                                  int C1, int C2, int C2p, int C1pad, float* __restrict__ dW2, float* __restrict__ dW3, float* __restrict__ db3,
-                                  float* __restrict__ db1, float* __restrict__ db2) {
+                                  const int* __restrict__ counters, int C1, int C2, int C2p, int C1pad, float* __restrict__ dW2,
+                                  float* __restrict__ dW3, float* __restrict__ db3, float* __restrict__ db1, float* __restrict__ db2) {
+    // slabs that were written: workgroups [0, min(nwg, small tiles)) of the main launch, then [nwg, nwg + min(nwg, big tiles)) of the
+    // big-graph launch
+    const int n_small = min(nwg, counters[0] - counters[2]), n_big = min(nwg, counters[2]);
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     const int64_t nW2 = (int64_t)C2 * C1;
     const float* p0;
@@ -577,12 +596,14 @@ __global__ void k_attn_bwd_reduce(const float* __restrict__ partW2, const float*
     }
     float a[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
     int s = 0;
-    for (; s + 8 <= nwg; s += 8) {
+    for (; s + 8 <= n_small; s += 8) {
 #pragma unroll
         for (int j = 0; j < 8; ++j) a[j] += p0[(size_t)(s + j) * stride];
     }
-    for (int j = 0; s < nwg; ++s, ++j) a[j] += p0[(size_t)s * stride];
-    *out = ((a[0] + a[1]) + (a[2] + a[3])) + ((a[4] + a[5]) + (a[6] + a[7]));
+    for (int j = 0; s < n_small; ++s, ++j) a[j] += p0[(size_t)s * stride];
+    float bsum = 0.f;
+    for (int k = 0; k < n_big; ++k) bsum += p0[(size_t)(nwg + k) * stride];
+    *out = (((a[0] + a[1]) + (a[2] + a[3])) + ((a[4] + a[5]) + (a[6] + a[7]))) + bsum;
 }
 
 static int bwd_nwg() {
@@ -633,21 +654,27 @@ size_t attn_fused_bwd_ws_bytes(const gsat_attn_args* a) {
     const size_t nwg = (size_t)bwd_nwg();
     size_t b = 256 + attn_plan_bytes(a->G);
     b += align_up((size_t)g.NCH * 2 * g.S2b * 2 * 64 * 16, 256);
-    b += align_up(nwg * g.C2p * g.C1pad * 4, 256) + align_up(nwg * g.C2p * 4, 256) + align_up(nwg * 4, 256);
+    b += align_up(2 * nwg * g.C2p * g.C1pad * 4, 256) + align_up(2 * nwg * g.C2p * 4, 256) + align_up(2 * nwg * 4, 256);      // small + big launch
     return b;
 }
 
-template <bool EDGE, int NCHT>
-static int launch_bwd(hipStream_t stream, const BwdArgs& ba, int grid) {
+template <bool EDGE, int NCHT, bool BIG>
+static int launch_bwd1(hipStream_t stream, const BwdArgs& ba, int grid) {
     static size_t allowed = 64 * 1024;
     const size_t lds = (size_t)ba.g.lds_bytes;
     if (lds > allowed) {
-        GSAT_CHECK_HIP(hipFuncSetAttribute((const void*)k_attn_fused_bwd<EDGE, NCHT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        GSAT_CHECK_HIP(hipFuncSetAttribute((const void*)k_attn_fused_bwd<EDGE, NCHT, BIG>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         allowed = lds;
     }
-    k_attn_fused_bwd<EDGE, NCHT><<<grid, BT, lds, stream>>>(ba);
+    k_attn_fused_bwd<EDGE, NCHT, BIG><<<grid, BT, lds, stream>>>(ba);
     GSAT_LAUNCH_CHECK();
     return GSAT_OK;
+}
+// whole-graph tiles, then (same grid; workgroups without a big tile exit at once) the graphs larger than a tile
+template <bool EDGE, int NCHT>
+static int launch_bwd(hipStream_t stream, const BwdArgs& ba, int grid) {
+    const int rc = launch_bwd1<EDGE, NCHT, false>(stream, ba, grid);
+    return rc ? rc : launch_bwd1<EDGE, NCHT, true>(stream, ba, grid);
 }
 
 // dh1 [M, C1] <- everything from (dlogits, datt) down to the layer-1 pre-activation; dW2, dW3, db3 written, db1 / db2 cleared
@@ -661,9 +688,13 @@ int attn_fused_bwd(hipStream_t stream, const gsat_attn_args* a, const gsat_attn_
     int* counters = reinterpret_cast<int*>(w); w += 256;
     FTile* tiles = reinterpret_cast<FTile*>(w); w += attn_plan_bytes(a->G);
     uint4* Wq2 = reinterpret_cast<uint4*>(w); w += align_up((size_t)g.NCH * 2 * g.S2b * 2 * 64 * 16, 256);
-    float* partW2 = reinterpret_cast<float*>(w); w += align_up((size_t)bwd_nwg() * g.C2p * g.C1pad * 4, 256);
-    float* partW3 = reinterpret_cast<float*>(w); w += align_up((size_t)bwd_nwg() * g.C2p * 4, 256);
+    float* partW2 = reinterpret_cast<float*>(w); w += align_up((size_t)2 * bwd_nwg() * g.C2p * g.C1pad * 4, 256);
+    float* partW3 = reinterpret_cast<float*>(w); w += align_up((size_t)2 * bwd_nwg() * g.C2p * 4, 256);
     float* partB3 = reinterpret_cast<float*>(w);
+#ifdef GSAT_FUSED_STAMPS
+    extern int* g_last_bwd_counters_ref(int*);
+    g_last_bwd_counters_ref(counters);
+#endif
     int rc = attn_plan_launch(stream, a->seg_ptr, a->seg_ptr, a->G, B_RM, B_RM, tiles, counters);
     if (rc) return rc;
     {
@@ -685,10 +716,23 @@ int attn_fused_bwd(hipStream_t stream, const gsat_attn_args* a, const gsat_attn_
 #undef GO
     if (rc) return rc;
     const int64_t total = (int64_t)a->C2 * a->C1 + a->C2 + 1 + a->C1 + a->C2;
-    k_attn_bwd_reduce<<<(unsigned)ceil_div(total, 256), 256, 0, stream>>>(partW2, partW3, partB3, nwg, a->C1, a->C2, g.C2p, g.C1pad, gr->dW2, gr->dW3,
-                                                                           gr->db3, gr->db1, gr->db2);
+    k_attn_bwd_reduce<<<(unsigned)ceil_div(total, 256), 256, 0, stream>>>(partW2, partW3, partB3, nwg, counters, a->C1, a->C2, g.C2p, g.C1pad, gr->dW2,
+                                                                           gr->dW3, gr->db3, gr->db1, gr->db2);
     GSAT_LAUNCH_CHECK();
     return GSAT_OK;
 }
 
 }  // namespace gsat
+
+#ifdef GSAT_FUSED_STAMPS
+// diagnostic builds only: host copy of the counters block of the last fused backward (tiles, -, big tiles, ..., stamp words from [16])
+static int* g_last_bwd_counters = nullptr;
+namespace gsat { int* g_last_bwd_counters_ref(int* p) { g_last_bwd_counters = p; return p; } }
+extern "C" const int* gsat_debug_bwd_counters(void) {
+    static int host[64];
+    if (!g_last_bwd_counters) return nullptr;
+    if (hipDeviceSynchronize() != hipSuccess) return nullptr;
+    if (hipMemcpy(host, g_last_bwd_counters, sizeof(host), hipMemcpyDeviceToHost) != hipSuccess) return nullptr;
+    return host;
+}
+#endif
