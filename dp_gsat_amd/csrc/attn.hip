@@ -845,6 +845,7 @@ size_t gsat_attn_bwd_workspace_bytes(const gsat_attn_args* a) {
     if (a->edge_mode) b += 2 * align_up(N * C1 * 4, 256) + align_up(gsat_long_row_partial_floats(a->M, a->C1) * 4, 256);   // dP, dQ, hub partials
     b += align_up(attn_gemm_ws_floats(a) * 4, 256);          // split-K slabs of the weight-gradient GEMMs
     if (attn_fused_bwd_eligible(a)) b += align_up(attn_fused_bwd_ws_bytes(a), 256);      // tiles, W2 fragment stream, per-workgroup partials
+    b += align_up(std::max(dual_gemm_ws_bytes(1, a->C2, a->C1, a->C1), dual_gemm_ws_bytes(2, a->C1, a->H, a->H)), 256);      // dual GEMMs: fragment stream + partial slabs
     return b + 1024;
 }
 
@@ -894,6 +895,8 @@ int gsat_attn_bwd(const gsat_attn_args* a, const gsat_attn_grads* gr, void* stre
     }
     GemmWs gws{nullptr, attn_gemm_ws_floats(a)};
     gws.ptr = ar.take<float>(gws.floats);
+    const size_t dws_bytes = std::max(dual_gemm_ws_bytes(1, C2, C1, C1), dual_gemm_ws_bytes(2, C1, H, H));
+    char* dws = ar.take<char>(dws_bytes);
     const bool fused_bwd = attn_fused_bwd_eligible(a) && seg_slices(M, G) == 1;
     const size_t fws_bytes = fused_bwd ? attn_fused_bwd_ws_bytes(a) : 0;
     char* fws = fused_bwd ? ar.take<char>(fws_bytes) : nullptr;
@@ -944,8 +947,12 @@ int gsat_attn_bwd(const gsat_attn_args* a, const gsat_attn_grads* gr, void* stre
         GSAT_LAUNCH_CHECK();
     }
     // dW2[C2,C1] = dh2^T a1 ; da1[M,C1] = dh2 W2
-    if ((rc = gemm_rm(stream, true, false, C2, C1, M, dh2, C2, a->a1, C1, 0.f, gr->dW2, C1, gws, true))) return rc;
-    if ((rc = gemm_rm(stream, false, false, M, C1, C2, dh2, C2, a->W2, C1, 0.f, da1, C1, GemmWs{nullptr, 0}, true))) return rc;
+    if (dual_gemm_ok(1, M, C2, C1, C1)) {            // both products in one pass over dh2 (dual_gemm.hip)
+        if ((rc = dual_gemm(stream, 1, M, C2, C1, C1, dh2, C2, a->a1, C1, a->W2, C1, da1, C1, 0, gr->dW2, C1, dws, dws_bytes))) return rc;
+    } else {
+        if ((rc = gemm_rm(stream, true, false, C2, C1, M, dh2, C2, a->a1, C1, 0.f, gr->dW2, C1, gws, true))) return rc;
+        if ((rc = gemm_rm(stream, false, false, M, C1, C2, dh2, C2, a->W2, C1, 0.f, da1, C1, GemmWs{nullptr, 0}, true))) return rc;
+    }
     // ---- through ReLU/dropout and the first InstanceNorm ---------------------------------------
     if (Z == 1) {        // statistics and dh1 (in place over da1) in one launch
         if (a->edge_mode) {
@@ -977,18 +984,27 @@ int gsat_attn_bwd(const gsat_attn_args* a, const gsat_attn_grads* gr, void* stre
         if ((rc = aggr_sum_fwd_impl(stream, da1, nullptr, nullptr, nullptr, gr->rowptr_dst, gr->eid_by_dst, nullptr, N, M, C1, 0.f, dQ,
                                     gr->chunk_ptr_dst, lpart))) return rc;
         // demb = dP W1a + dQ W1b ; dW1[:, :H] = dP^T emb ; dW1[:, H:] = dQ^T emb
+        if (dual_gemm_ok(2, N, C1, H, H)) {
+            if ((rc = dual_gemm(stream, 2, N, C1, H, H, dP, C1, a->emb, H, a->W1, 2 * H, gr->demb, H, 0, gr->dW1, 2 * H, dws, dws_bytes))) return rc;
+            if ((rc = dual_gemm(stream, 2, N, C1, H, H, dQ, C1, a->emb, H, a->W1 + H, 2 * H, gr->demb, H, 1, gr->dW1 + H, 2 * H, dws, dws_bytes))) return rc;
+        } else {
         if ((rc = gemm_rm(stream, false, false, N, H, C1, dP, C1, a->W1, 2 * H, 0.f, gr->demb, H, GemmWs{nullptr, 0}, true))) return rc;
         if ((rc = gemm_rm(stream, false, false, N, H, C1, dQ, C1, a->W1 + H, 2 * H, 1.f, gr->demb, H, GemmWs{nullptr, 0}, true))) return rc;
         if ((rc = gemm_rm(stream, true, false, C1, H, N, dP, C1, a->emb, H, 0.f, gr->dW1, 2 * H, gws, true))) return rc;
         if ((rc = gemm_rm(stream, true, false, C1, H, N, dQ, C1, a->emb, H, 0.f, gr->dW1 + H, 2 * H, gws, true))) return rc;
+        }
     } else {
         if (Z > 1) {
             PreAct<false> pre{a->P, nullptr, a->b1, nullptr, nullptr, C1};
             k_dh1<false><<<ew_blocks(M * (C1 / 4)), 256, 0, stream>>>(pre, a->row_seg, mean1, rstd1, a->a1, sc, S1p, S2p, M, da1);
             GSAT_LAUNCH_CHECK();
         }
+        if (dual_gemm_ok(2, N, C1, H, H)) {
+            if ((rc = dual_gemm(stream, 2, N, C1, H, H, da1, C1, a->emb, H, a->W1, H, gr->demb, H, 0, gr->dW1, H, dws, dws_bytes))) return rc;
+        } else {
         if ((rc = gemm_rm(stream, false, false, N, H, C1, da1, C1, a->W1, H, 0.f, gr->demb, H, GemmWs{nullptr, 0}, true))) return rc;
         if ((rc = gemm_rm(stream, true, false, C1, H, N, da1, C1, a->emb, H, 0.f, gr->dW1, H, gws, true))) return rc;
+        }
     }
     return GSAT_OK;
 }

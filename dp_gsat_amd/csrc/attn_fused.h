@@ -34,6 +34,12 @@ bool attn_fused_bwd_eligible(const gsat_attn_args* a);
 size_t attn_fused_bwd_ws_bytes(const gsat_attn_args* a);
 int attn_fused_bwd(hipStream_t stream, const gsat_attn_args* a, const gsat_attn_grads* gr, float* dh1, void* ws, size_t ws_bytes);
 
+// dual split-bf16 tile GEMMs (dual_gemm.hip): OUT [R, NO] (+)= A W and DW [KA, KY] = A^T Y in one pass over the rows
+bool dual_gemm_ok(int mode, int64_t R, int KA, int KY, int NO);
+size_t dual_gemm_ws_bytes(int mode, int KA, int KY, int NO);
+int dual_gemm(hipStream_t stream, int mode, int64_t R, int KA, int KY, int NO, const float* A, int lda, const float* Y, int ldy, const float* W,
+              int ldw, float* OUT, int ldo, int accumulate, float* DW, int lddw, void* ws, size_t ws_bytes);
+
 #ifdef __HIPCC__
 // dropout keep-mask of 4 consecutive channels: explicit tensor, or Philox keyed by (seed, layer, row, column) -- the same draw as
 // gsat_philox_keep_mask and the unfused kernels of attn.hip
