@@ -96,6 +96,12 @@ __global__ void k_dual_pack(const float* __restrict__ W, int ldw, int KA, int NO
     }
 }
 
+#ifdef GSAT_FUSED_STAMPS
+__device__ unsigned long long g_dual_stamps[2][8];
+#define DSTAMP(i) do { if (tid == 0) { const long long n_ = __builtin_amdgcn_s_memtime(); dst_[i] += n_ - dtl_; dtl_ = n_; } } while (0)
+#else
+#define DSTAMP(i)
+#endif
 template <int MODE>
 __global__ __launch_bounds__(DT, 2) void k_dual_gemm(const DualArgs P) {
     extern __shared__ __attribute__((aligned(16))) unsigned char dsm[];
@@ -108,8 +114,8 @@ __global__ __launch_bounds__(DT, 2) void k_dual_gemm(const DualArgs P) {
     const int ldc = MODE == 1 ? P.ldy : P.lda, Cext = MODE == 1 ? P.KY : P.KA;
     const float* const Rg = MODE == 1 ? P.A : P.Y;
     const int ldr = MODE == 1 ? P.lda : P.ldy, Rext = MODE == 1 ? P.KA : P.KY, Rextp = MODE == 1 ? P.KAp : P.KYp;
-    f32x16 accW[D_MAXCH];
-    for (int k = 0; k < D_MAXCH; ++k)
+    f32x16 accW[D_MAXCH];                               // DW accumulators of the chunks (dynamically indexed: they live in scratch; the
+    for (int k = 0; k < D_MAXCH; ++k)                   // chunk loop loads its accumulator FIRST, before any long-latency prefetch)
 #pragma unroll
         for (int r = 0; r < 16; ++r) accW[k][r] = 0.f;
     // chunk rows staged in registers: 128 rows x 64 floats = 2048 float4 / 512 threads = 4 per thread
@@ -131,17 +137,31 @@ __global__ __launch_bounds__(DT, 2) void k_dual_gemm(const DualArgs P) {
         }
     };
 
+#ifdef GSAT_FUSED_STAMPS
+    long long dst_[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    long long dtl_ = __builtin_amdgcn_s_memtime();
+#endif
     for (int t = blockIdx.x; t < P.ntiles; t += gridDim.x) {
         const int64_t row0 = (int64_t)t * D_RM;
         d_barrier();                                        // the previous tile's planes are consumed
         // resident operand -> planes (zero beyond the matrix: padded columns and rows contribute nothing)
         {
+            // batches of four 16-byte loads per thread in flight (a plain loop waits for every load before it issues the next: eight serial
+            // HBM latencies per tile)
             const int W4 = Rextp >> 2;
-            for (int i = tid; i < D_RM * W4; i += DT) {
-                const int r = i / W4, q = i - r * W4;
-                const int64_t row = row0 + r;
-                const float4 v = (row < P.R && 4 * q < Rext) ? ld4(Rg + (size_t)row * ldr + 4 * q) : f4zero();
-                d_store_split(Rhi, Rlo, r * SBR + q * 8, v);
+            for (int i0 = tid; i0 < D_RM * W4; i0 += 4 * DT) {
+                float4 v[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const int i = i0 + u * DT, r = i / W4, q = i - r * W4;
+                    const int64_t row = row0 + r;
+                    v[u] = (i < D_RM * W4 && row < P.R && 4 * q < Rext) ? ld4(Rg + (size_t)row * ldr + 4 * q) : f4zero();
+                }
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const int i = i0 + u * DT, r = i / W4, q = i - r * W4;
+                    if (i < D_RM * W4) d_store_split(Rhi, Rlo, r * SBR + q * 8, v[u]);
+                }
             }
         }
         chunk_load(row0, 0);
@@ -150,31 +170,62 @@ __global__ __launch_bounds__(DT, 2) void k_dual_gemm(const DualArgs P) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) { accO[0][r] = 0.f; accO[1][r] = 0.f; }
         d_barrier();
+        DSTAMP(0);
         for (int c = 0; c < P.nch; ++c) {
+            {
+            f32x16 accC = accW[c];
             unsigned char* const Chi = dsm + ((c & 1) ? P.offC1 : P.offC0);
             unsigned char* const Clo = Chi + D_RM * D_SBC;
-            if (c + 1 < P.nch) chunk_load(row0, c + 1);                 // in flight under this chunk's MFMAs
             if (MODE == 1) {
+                // Loads in the order they are needed (vmcnt retires in order): this chunk's weight fragments first, THEN the prefetch of
+                // the next chunk's rows -- issued the other way round, the first MFMA would wait for the prefetch's HBM latency.
+                const int rb = wave >> 1, cb = wave & 1;
+                const uint4* bp = P.Wq + ((size_t)((c * 2 + cb) * P.S) * 2) * 64 + lane;
+                uint4 wq[16];                                           // S <= 8 steps x (hi, lo)
+#pragma unroll
+                for (int s = 0; s < 8; ++s) {
+                    const int sc_ = min(s, P.S - 1);
+                    wq[2 * s] = bp[(size_t)sc_ * 128]; wq[2 * s + 1] = bp[(size_t)sc_ * 128 + 64];
+                }
+                if (c + 1 < P.nch) chunk_load(row0, c + 1);             // in flight under this chunk's MFMAs
+                // DW[:, chunk] += A^T Y[:, chunk]: (KAp / 32) x 2 tiles, one per wave; k = the 128 tile rows
+                {
+                    const int ib = wave >> 1, jb = wave & 1;
+                    if (ib * 32 < P.KAp) {
+                        const int gq = lane >> 4, hh = gq >> 1, c16 = (gq & 1) * 16;
+                        f32x16 acc = accC;
+#pragma unroll 2
+                        for (int s = 0; s < D_RM / 16; ++s) {
+                            const int r0 = 16 * s + 8 * hh;
+                            const bf16x8 ah = d_tr_frag(Rhi, SBR, r0, ib * 32 + c16, lane);
+                            const bf16x8 al = d_tr_frag(Rlo, SBR, r0, ib * 32 + c16, lane);
+                            const bf16x8 bh = d_tr_frag(Chi, D_SBC, r0, jb * 32 + c16, lane);
+                            const bf16x8 bl = d_tr_frag(Clo, D_SBC, r0, jb * 32 + c16, lane);
+                            acc = D_MFMA(al, bh, acc);
+                            acc = D_MFMA(ah, bl, acc);
+                            acc = D_MFMA(ah, bh, acc);
+                        }
+                        accC = acc;
+                    }
+                }
+                DSTAMP(1);
                 // OUT[:, chunk] = A W[:, chunk]: 4 row blocks x 2 column blocks, one per wave; k = KA
                 {
-                    const int rb = wave >> 1, cb = wave & 1;
                     f32x16 acc;
 #pragma unroll
                     for (int r = 0; r < 16; ++r) acc[r] = 0.f;
                     const unsigned char* ah = Rhi + (rb * 32 + (lane & 31)) * SBR + (lane >> 5) * 16;
                     const unsigned char* al = ah + D_RM * SBR;
-                    const uint4* bp = P.Wq + ((size_t)((c * 2 + cb) * P.S) * 2) * 64 + lane;
-                    uint4 wh = bp[0], wl = bp[64];
-                    for (int s = 0; s < P.S; ++s) {
-                        const int sn = min(s + 1, P.S - 1);
-                        const uint4 nh = bp[(size_t)sn * 128], nl = bp[(size_t)sn * 128 + 64];
-                        const bf16x8 xh = *reinterpret_cast<const bf16x8*>(ah + s * 32);
-                        const bf16x8 xl = *reinterpret_cast<const bf16x8*>(al + s * 32);
-                        const bf16x8 bh = __builtin_bit_cast(bf16x8, wh), bl = __builtin_bit_cast(bf16x8, wl);
-                        acc = D_MFMA(xl, bh, acc);
-                        acc = D_MFMA(xh, bl, acc);
-                        acc = D_MFMA(xh, bh, acc);
-                        wh = nh; wl = nl;
+#pragma unroll
+                    for (int s = 0; s < 8; ++s) {
+                        if (s < P.S) {
+                            const bf16x8 xh = *reinterpret_cast<const bf16x8*>(ah + s * 32);
+                            const bf16x8 xl = *reinterpret_cast<const bf16x8*>(al + s * 32);
+                            const bf16x8 bh = __builtin_bit_cast(bf16x8, wq[2 * s]), bl = __builtin_bit_cast(bf16x8, wq[2 * s + 1]);
+                            acc = D_MFMA(xl, bh, acc);
+                            acc = D_MFMA(xh, bl, acc);
+                            acc = D_MFMA(xh, bh, acc);
+                        }
                     }
                     const int col = c * D_CH + cb * 32 + (lane & 31);
                     if (col < P.NO) {
@@ -188,27 +239,18 @@ __global__ __launch_bounds__(DT, 2) void k_dual_gemm(const DualArgs P) {
                         }
                     }
                 }
-                // DW[:, chunk] += A^T Y[:, chunk]: (KAp / 32) x 2 tiles, one per wave; k = the 128 tile rows
-                {
-                    const int ib = wave >> 1, jb = wave & 1;
-                    if (ib * 32 < P.KAp) {
-                        const int gq = lane >> 4, hh = gq >> 1, c16 = (gq & 1) * 16;
-                        f32x16 acc = accW[c];
-                        for (int s = 0; s < D_RM / 16; ++s) {
-                            const int r0 = 16 * s + 8 * hh;
-                            const bf16x8 ah = d_tr_frag(Rhi, SBR, r0, ib * 32 + c16, lane);
-                            const bf16x8 al = d_tr_frag(Rlo, SBR, r0, ib * 32 + c16, lane);
-                            const bf16x8 bh = d_tr_frag(Chi, D_SBC, r0, jb * 32 + c16, lane);
-                            const bf16x8 bl = d_tr_frag(Clo, D_SBC, r0, jb * 32 + c16, lane);
-                            acc = D_MFMA(al, bh, acc);
-                            acc = D_MFMA(ah, bl, acc);
-                            acc = D_MFMA(ah, bh, acc);
-                        }
-                        accW[c] = acc;
-                    }
-                }
             } else {
-                // OUT += A[:, chunk] W[chunk, :]: 4 row blocks x ncb column blocks, two per wave; k = 64
+                // OUT += A[:, chunk] W[chunk, :]: 4 row blocks x ncb column blocks, two per wave; k = 64.  Weight fragments first, then the
+                // prefetch of the next chunk's rows (see MODE 1)
+                uint4 wq[16];
+#pragma unroll
+                for (int u = 0; u < 2; ++u) {
+                    const int cb = min(2 * (wave & 1) + u, P.ncb - 1);
+                    const uint4* bp = P.Wq + ((size_t)((c * P.ncb + cb) * 4) * 2) * 64 + lane;
+#pragma unroll
+                    for (int s = 0; s < 4; ++s) { wq[u * 8 + 2 * s] = bp[(size_t)s * 128]; wq[u * 8 + 2 * s + 1] = bp[(size_t)s * 128 + 64]; }
+                }
+                if (c + 1 < P.nch) chunk_load(row0, c + 1);
                 {
                     const int rb = wave >> 1;
                     const unsigned char* ah = Chi + (rb * 32 + (lane & 31)) * D_SBC + (lane >> 5) * 16;
@@ -217,11 +259,10 @@ __global__ __launch_bounds__(DT, 2) void k_dual_gemm(const DualArgs P) {
                     for (int u = 0; u < 2; ++u) {
                         const int cb = 2 * (wave & 1) + u;
                         if (cb < P.ncb) {
-                            const uint4* bp = P.Wq + ((size_t)((c * P.ncb + cb) * 4) * 2) * 64 + lane;
                             f32x16 acc = accO[u];
 #pragma unroll
                             for (int s = 0; s < 4; ++s) {
-                                const uint4 wh = bp[(size_t)s * 128], wl = bp[(size_t)s * 128 + 64];
+                                const uint4 wh = wq[u * 8 + 2 * s], wl = wq[u * 8 + 2 * s + 1];
                                 const bf16x8 xh = *reinterpret_cast<const bf16x8*>(ah + s * 32);
                                 const bf16x8 xl = *reinterpret_cast<const bf16x8*>(al + s * 32);
                                 const bf16x8 bh = __builtin_bit_cast(bf16x8, wh), bl = __builtin_bit_cast(bf16x8, wl);
@@ -238,7 +279,7 @@ __global__ __launch_bounds__(DT, 2) void k_dual_gemm(const DualArgs P) {
                     const int ib = wave >> 2, jb = wave & 3;
                     if (jb * 32 < P.KYp) {
                         const int gq = lane >> 4, hh = gq >> 1, c16 = (gq & 1) * 16;
-                        f32x16 acc = accW[c];
+                        f32x16 acc = accC;
                         for (int s = 0; s < D_RM / 16; ++s) {
                             const int r0 = 16 * s + 8 * hh;
                             const bf16x8 ah = d_tr_frag(Chi, D_SBC, r0, ib * 32 + c16, lane);
@@ -249,12 +290,16 @@ __global__ __launch_bounds__(DT, 2) void k_dual_gemm(const DualArgs P) {
                             acc = D_MFMA(ah, bl, acc);
                             acc = D_MFMA(ah, bh, acc);
                         }
-                        accW[c] = acc;
+                        accC = acc;
                     }
                 }
             }
+            DSTAMP(2);
+            accW[c] = accC;
             if (c + 1 < P.nch) chunk_store(dsm + ((c & 1) ? P.offC0 : P.offC1));      // nobody reads the other buffer during this chunk
             d_barrier();
+            DSTAMP(3);
+            }
         }
         if (MODE == 2) {
             const int rb = wave >> 1;
@@ -275,6 +320,7 @@ __global__ __launch_bounds__(DT, 2) void k_dual_gemm(const DualArgs P) {
             }
         }
     }
+    DSTAMP(4);
     // this workgroup's partial of DW: [KAp, ldpart]; MODE 1: rows = KA blocks (wave >> 1), columns = chunk*64 + (wave & 1)*32;
     // MODE 2: rows = chunk*64 + (wave >> 2)*32, columns = (wave & 3)*32
     float* const pw = P.part + (size_t)blockIdx.x * P.KAp * P.ldpart;
@@ -291,27 +337,42 @@ __global__ __launch_bounds__(DT, 2) void k_dual_gemm(const DualArgs P) {
             }
         }
     }
+#ifdef GSAT_FUSED_STAMPS
+    DSTAMP(5);
+    if (tid == 0) { for (int i = 0; i < 6; ++i) atomicAdd(&g_dual_stamps[MODE - 1][i], (unsigned long long)dst_[i]); atomicAdd(&g_dual_stamps[MODE - 1][7], 1ull); }
+#endif
 }
 
-// DW[k, j] = sum over the workgroup slabs (fixed order); four threads share an output element (slabs q, q + 4, ...) and combine in a fixed
-// tree, eight loads in flight each
+// DW[k, j..j+3] = sum over the workgroup slabs (fixed order): four lanes share a float4 of the output (lane q takes slabs q, q + 4, ...,
+// two partial sums in flight), 16-byte loads, then a fixed tree over the quad
 __global__ void k_dual_reduce(const float* __restrict__ part, int nslab, size_t slab_stride, int rows, int cols, int ldpart, float* __restrict__ out,
                               int ldout) {
     const int64_t tg = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     const int q = (int)(tg & 3);
-    const int64_t i = tg >> 2;
-    const bool live = i < (int64_t)rows * cols;
-    float a[4] = {0.f, 0.f, 0.f, 0.f};
+    const int64_t i4 = tg >> 2;
+    const int c4 = cols >> 2;
+    const bool live = i4 < (int64_t)rows * c4;
+    float4 a = f4zero(), b = f4zero();
+    int r = 0, c = 0;
     if (live) {
-        const int r = (int)(i / cols), c = (int)(i % cols);
+        r = (int)(i4 / c4); c = (int)(i4 % c4) * 4;
         const float* p0 = part + (size_t)r * ldpart + c;
-        int s = q, j = 0;
-        for (; s < nslab; s += 4, j = (j + 1) & 3) a[j] += p0[(size_t)s * slab_stride];
+        int s = q;
+        for (; s + 4 < nslab; s += 8) {
+            const float4 v0 = ld4(p0 + (size_t)s * slab_stride), v1 = ld4(p0 + (size_t)(s + 4) * slab_stride);
+            a.x += v0.x; a.y += v0.y; a.z += v0.z; a.w += v0.w;
+            b.x += v1.x; b.y += v1.y; b.z += v1.z; b.w += v1.w;
+        }
+        if (s < nslab) { const float4 v0 = ld4(p0 + (size_t)s * slab_stride); a.x += v0.x; a.y += v0.y; a.z += v0.z; a.w += v0.w; }
     }
-    float v = (a[0] + a[1]) + (a[2] + a[3]);
-    v += __shfl_xor(v, 1, 64);
-    v += __shfl_xor(v, 2, 64);
-    if (live && q == 0) { const int r = (int)(i / cols), c = (int)(i % cols); out[(size_t)r * ldout + c] = v; }
+    float4 v = make_float4(a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w);
+    v.x += __shfl_xor(v.x, 1, 64); v.y += __shfl_xor(v.y, 1, 64); v.z += __shfl_xor(v.z, 1, 64); v.w += __shfl_xor(v.w, 1, 64);
+    v.x += __shfl_xor(v.x, 2, 64); v.y += __shfl_xor(v.y, 2, 64); v.z += __shfl_xor(v.z, 2, 64); v.w += __shfl_xor(v.w, 2, 64);
+    if (live && q == 0) {
+        float* o = out + (size_t)r * ldout + c;
+        if ((ldout & 3) == 0 && ((uintptr_t)out & 15) == 0) st4(o, v);
+        else { o[0] = v.x; o[1] = v.y; o[2] = v.z; o[3] = v.w; }
+    }
 }
 
 static int dual_nwg() {
@@ -326,8 +387,11 @@ static int dual_nwg() {
 }
 
 bool dual_gemm_ok(int mode, int64_t R, int KA, int KY, int NO) {
+    // opt-in (GSAT_DUAL_GEMM=1): measured on MI355X the one-pass kernels do not beat the GEMM pairs they replace yet (C3: 94 / 79 us + 13 us
+    // reductions against 58 + 40 us): one 143 KB workgroup per CU leaves its row loads, weight-fragment loads and MFMAs un-overlapped
+    // (profiles/r03_summary.md has the phase stamps)
     const char* env = getenv("GSAT_DUAL_GEMM");
-    if (env && atoi(env) == 0) return false;
+    if (!(env && atoi(env) != 0)) return false;
     if (R <= 0 || KA % 4 || KY % 4 || NO % 4) return false;
     if (mode == 1) return KA <= 128 && NO == KY && KY <= D_MAXCH * D_CH;
     return KY <= 128 && NO == KY && KA <= D_MAXCH * D_CH;
@@ -374,20 +438,33 @@ int dual_gemm(hipStream_t stream, int mode, int64_t R, int KA, int KY, int NO, c
         GSAT_LAUNCH_CHECK();
     }
     static size_t allowed1 = 64 * 1024, allowed2 = 64 * 1024;
+    if (lds > allowed1) {
+        GSAT_CHECK_HIP(hipFuncSetAttribute((const void*)k_dual_gemm<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        GSAT_CHECK_HIP(hipFuncSetAttribute((const void*)k_dual_gemm<2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        allowed1 = lds;
+    }
+    (void)allowed2;
     if (mode == 1) {
-        if (lds > allowed1) { GSAT_CHECK_HIP(hipFuncSetAttribute((const void*)k_dual_gemm<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); allowed1 = lds; }
         k_dual_gemm<1><<<nwg, DT, lds, stream>>>(P);
     } else {
         DualArgs Q = P;
         Q.KAp = prow;                                             // slab rows (see above); the padded A extent is not used by MODE 2
-        if (lds > allowed2) { GSAT_CHECK_HIP(hipFuncSetAttribute((const void*)k_dual_gemm<2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); allowed2 = lds; }
         k_dual_gemm<2><<<nwg, DT, lds, stream>>>(Q);
     }
     GSAT_LAUNCH_CHECK();
     const int64_t outs = (int64_t)KA * KY;
-    k_dual_reduce<<<(unsigned)ceil_div(outs * 4, 256), 256, 0, stream>>>(P.part, nwg, (size_t)prow * P.ldpart, KA, KY, P.ldpart, DW, lddw);
+    k_dual_reduce<<<(unsigned)ceil_div(outs, 256), 256, 0, stream>>>(P.part, nwg, (size_t)prow * P.ldpart, KA, KY, P.ldpart, DW, lddw);
     GSAT_LAUNCH_CHECK();
     return GSAT_OK;
 }
 
 }  // namespace gsat
+
+#ifdef GSAT_FUSED_STAMPS
+extern "C" const unsigned long long* gsat_debug_dual_stamps(void) {
+    static unsigned long long host[16];
+    if (hipDeviceSynchronize() != hipSuccess) return nullptr;
+    if (hipMemcpyFromSymbol(host, HIP_SYMBOL(gsat::g_dual_stamps), sizeof(host)) != hipSuccess) return nullptr;
+    return host;
+}
+#endif

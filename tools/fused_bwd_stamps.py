@@ -12,7 +12,7 @@ sys.path.insert(0, ROOT)
 
 
 def main(wl="c3"):
-    os.environ["GSAT_ATTN_BWD_FUSED"] = "1"
+    os.environ.setdefault("GSAT_ATTN_BWD_FUSED", "1")
     import bench
     import dp_gsat_amd as G
     from dp_gsat_amd import _lib
@@ -28,6 +28,16 @@ def main(wl="c3"):
         z, a = ext.attend(emb, data.edge_index, data.batch, noise="philox")
         torch.autograd.backward([z, a], [torch.ones_like(z), torch.ones_like(a)])
     lib = _lib.load()
+    if os.environ.get("GSAT_ATTN_BWD_FUSED") != "1":
+        lib.gsat_debug_dual_stamps.restype = ctypes.POINTER(ctypes.c_ulonglong * 16)
+        d = list(lib.gsat_debug_dual_stamps().contents)
+        for mode in (0, 1):
+            v = d[mode * 8:mode * 8 + 8]
+            n = max(v[7], 1)
+            print(f"dual MODE {mode + 1}: workgroup-runs {v[7]}")
+            for nme, x in zip(["0 resident + chunk 0", "1 weights + DW product", "2 row product + stores", "3 chunk store + barrier", "4 tile tail", "5 partials"], v[:6]):
+                print(f"   {nme:26s} {x / n:10.0f} cycles per workgroup-run")
+        return
     lib.gsat_debug_bwd_counters.restype = ctypes.POINTER(ctypes.c_int * 64)
     c = lib.gsat_debug_bwd_counters().contents
     vals = list(c)
