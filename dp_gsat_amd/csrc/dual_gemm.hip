@@ -102,155 +102,164 @@ __device__ unsigned long long g_dual_stamps[2][8];
 #else
 #define DSTAMP(i)
 #endif
+
+// LDS: resident planes [128][SBR] hi | lo, chunk planes [128][D_SBC] hi | lo, the chunk's weight fragments (fragment order, shared by the
+// waves).  Everything the NEXT step needs (rows of the next chunk, its weight fragments, at a tile's last chunk also the next tile's
+// resident rows and first chunk) is fetched into registers while the current chunk's MFMAs run, and written to LDS behind a barrier:
+// the only exposed memory latency is the kernel's very first fill.
 template <int MODE>
 __global__ __launch_bounds__(DT, 2) void k_dual_gemm(const DualArgs P) {
     extern __shared__ __attribute__((aligned(16))) unsigned char dsm[];
-    unsigned char* const Rhi = dsm;                                  // resident planes: [128][SBR] hi | lo   (MODE 1: A, MODE 2: Y)
+    unsigned char* const Rhi = dsm;
     unsigned char* const Rlo = dsm + D_RM * P.SBR;
+    unsigned char* const Chi = dsm + P.offC0;
+    unsigned char* const Clo = Chi + D_RM * D_SBC;
+    uint4* const Wl = reinterpret_cast<uint4*>(dsm + P.offC1);           // [ncb][S][2][64] fragments of the chunk
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int SBR = P.SBR;
-    // the chunked operand: MODE 1: Y (and OUT columns), MODE 2: A (the k extent of OUT)
     const float* const Cg = MODE == 1 ? P.Y : P.A;
     const int ldc = MODE == 1 ? P.ldy : P.lda, Cext = MODE == 1 ? P.KY : P.KA;
     const float* const Rg = MODE == 1 ? P.A : P.Y;
     const int ldr = MODE == 1 ? P.lda : P.ldy, Rext = MODE == 1 ? P.KA : P.KY, Rextp = MODE == 1 ? P.KAp : P.KYp;
-    f32x16 accW[D_MAXCH];                               // DW accumulators of the chunks (dynamically indexed: they live in scratch; the
-    for (int k = 0; k < D_MAXCH; ++k)                   // chunk loop loads its accumulator FIRST, before any long-latency prefetch)
+    const int W4 = Rextp >> 2;                          // float4 per resident row: 128 * W4 / 512 <= 8 per thread
+    const int wfrag = P.ncb * P.S * 2 * 64;             // uint4 per chunk of the weight stream (<= 2048: 4 per thread)
+    f32x16 accW[D_MAXCH];
+    for (int k = 0; k < D_MAXCH; ++k)
 #pragma unroll
         for (int r = 0; r < 16; ++r) accW[k][r] = 0.f;
-    // chunk rows staged in registers: 128 rows x 64 floats = 2048 float4 / 512 threads = 4 per thread
-    float4 stg[4];
-    auto chunk_load = [&](int64_t row0, int c) {
+    // Prefetch loads are UNCONDITIONAL (addresses clamped into the matrix, the out-of-range lanes are zeroed when the registers are
+    // written to LDS): a load under `cond ? load : 0` compiles to a branch with `s_waitcnt vmcnt(0)` at its merge, i.e. no prefetch at all.
+    // The staging registers are plain scalars (arrays captured by the lambdas of an earlier version stayed in scratch, which also
+    // serialises: a scratch store needs the loaded value at once).
+    float4 rq0 = f4zero(), rq1 = f4zero(), rq2 = f4zero(), rq3 = f4zero();
+    uint4 wq0 = make_uint4(0u, 0u, 0u, 0u), wq1 = wq0, wq2 = wq0, wq3 = wq0;
+    int64_t pf_row0 = 0;
+    int pf_c = 0;
+#define D_ROWS_LOAD(ROW0, C)                                                                                                   \
+    {                                                                                                                          \
+        pf_row0 = (ROW0); pf_c = (C);                                                                                          \
+        const int q_ = tid & 15, r_ = tid >> 4;                                                                                \
+        const int col_ = min(pf_c * D_CH + 4 * q_, Cext - 4);                                                                  \
+        rq0 = ld4(Cg + (size_t)min(pf_row0 + r_, P.R - 1) * ldc + col_);                                                       \
+        rq1 = ld4(Cg + (size_t)min(pf_row0 + r_ + 32, P.R - 1) * ldc + col_);                                                  \
+        rq2 = ld4(Cg + (size_t)min(pf_row0 + r_ + 64, P.R - 1) * ldc + col_);                                                  \
+        rq3 = ld4(Cg + (size_t)min(pf_row0 + r_ + 96, P.R - 1) * ldc + col_);                                                  \
+    }
+#define D_ROWS_STORE()                                                                                                         \
+    {                                                                                                                          \
+        const int q_ = tid & 15, r_ = tid >> 4;                                                                                \
+        const bool cin_ = pf_c * D_CH + 4 * q_ < Cext;                                                                         \
+        d_store_split(Chi, Clo, r_ * D_SBC + q_ * 8, (cin_ && pf_row0 + r_ < P.R) ? rq0 : f4zero());                           \
+        d_store_split(Chi, Clo, (r_ + 32) * D_SBC + q_ * 8, (cin_ && pf_row0 + r_ + 32 < P.R) ? rq1 : f4zero());               \
+        d_store_split(Chi, Clo, (r_ + 64) * D_SBC + q_ * 8, (cin_ && pf_row0 + r_ + 64 < P.R) ? rq2 : f4zero());               \
+        d_store_split(Chi, Clo, (r_ + 96) * D_SBC + q_ * 8, (cin_ && pf_row0 + r_ + 96 < P.R) ? rq3 : f4zero());               \
+    }
+#define D_W_LOAD(C)                                                                                                            \
+    {                                                                                                                          \
+        const uint4* wp_ = P.Wq + (size_t)(C) * wfrag;                                                                         \
+        wq0 = wp_[min(tid, wfrag - 1)]; wq1 = wp_[min(tid + DT, wfrag - 1)];                                                   \
+        wq2 = wp_[min(tid + 2 * DT, wfrag - 1)]; wq3 = wp_[min(tid + 3 * DT, wfrag - 1)];                                      \
+    }
+#define D_W_STORE()                                                                                                            \
+    {                                                                                                                          \
+        if (tid < wfrag) Wl[tid] = wq0;                                                                                        \
+        if (tid + DT < wfrag) Wl[tid + DT] = wq1;                                                                              \
+        if (tid + 2 * DT < wfrag) Wl[tid + 2 * DT] = wq2;                                                                      \
+        if (tid + 3 * DT < wfrag) Wl[tid + 3 * DT] = wq3;                                                                      \
+    }
+    // resident rows of a tile -> planes, two batches of four 16-byte loads per thread
+    auto res_fill = [&](int64_t row0) {
+#pragma unroll 1
+        for (int hb = 0; hb < 2; ++hb) {
+            float4 v[4];
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            const int i = tid + u * DT, r = i >> 4, q = i & 15;
-            const int col = c * D_CH + 4 * q;
-            const int64_t row = row0 + r;
-            stg[u] = (row < P.R && col < Cext) ? ld4(Cg + (size_t)row * ldc + col) : f4zero();
+            for (int u = 0; u < 4; ++u) {
+                const int i = min(tid + (hb * 4 + u) * DT, D_RM * W4 - 1), r = i / W4, q = i - r * W4;
+                const int64_t row = min(row0 + r, P.R - 1);
+                v[u] = ld4(Rg + (size_t)row * ldr + min(4 * q, Rext - 4));
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int i = tid + (hb * 4 + u) * DT, r = i / W4, q = i - r * W4;
+                const bool in = row0 + r < P.R && 4 * q < Rext;
+                if (i < D_RM * W4) d_store_split(Rhi, Rlo, r * SBR + q * 8, in ? v[u] : f4zero());
+            }
         }
     };
-    auto chunk_store = [&](unsigned char* buf) {
-#pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            const int i = tid + u * DT, r = i >> 4, q = i & 15;
-            d_store_split(buf, buf + D_RM * D_SBC, r * D_SBC + q * 8, stg[u]);
-        }
-    };
-
 #ifdef GSAT_FUSED_STAMPS
     long long dst_[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     long long dtl_ = __builtin_amdgcn_s_memtime();
 #endif
+    if ((int)blockIdx.x < P.ntiles) {
+        const int64_t row0 = (int64_t)blockIdx.x * D_RM;
+        D_ROWS_LOAD(row0, 0) D_W_LOAD(0)
+        res_fill(row0);
+        D_ROWS_STORE() D_W_STORE()
+    }
+    d_barrier();
+    DSTAMP(0);
     for (int t = blockIdx.x; t < P.ntiles; t += gridDim.x) {
         const int64_t row0 = (int64_t)t * D_RM;
-        d_barrier();                                        // the previous tile's planes are consumed
-        // resident operand -> planes (zero beyond the matrix: padded columns and rows contribute nothing)
-        {
-            // batches of four 16-byte loads per thread in flight (a plain loop waits for every load before it issues the next: eight serial
-            // HBM latencies per tile)
-            const int W4 = Rextp >> 2;
-            for (int i0 = tid; i0 < D_RM * W4; i0 += 4 * DT) {
-                float4 v[4];
-#pragma unroll
-                for (int u = 0; u < 4; ++u) {
-                    const int i = i0 + u * DT, r = i / W4, q = i - r * W4;
-                    const int64_t row = row0 + r;
-                    v[u] = (i < D_RM * W4 && row < P.R && 4 * q < Rext) ? ld4(Rg + (size_t)row * ldr + 4 * q) : f4zero();
-                }
-#pragma unroll
-                for (int u = 0; u < 4; ++u) {
-                    const int i = i0 + u * DT, r = i / W4, q = i - r * W4;
-                    if (i < D_RM * W4) d_store_split(Rhi, Rlo, r * SBR + q * 8, v[u]);
-                }
-            }
-        }
-        chunk_load(row0, 0);
-        chunk_store(dsm + P.offC0);
+        const int tn = t + (int)gridDim.x;
         f32x16 accO[2];
 #pragma unroll
         for (int r = 0; r < 16; ++r) { accO[0][r] = 0.f; accO[1][r] = 0.f; }
-        d_barrier();
-        DSTAMP(0);
         for (int c = 0; c < P.nch; ++c) {
-            {
-            f32x16 accC = accW[c];
-            unsigned char* const Chi = dsm + ((c & 1) ? P.offC1 : P.offC0);
-            unsigned char* const Clo = Chi + D_RM * D_SBC;
+            f32x16 accC = accW[c];                                  // (scratch) before the prefetches: vmcnt retires in order
+            const bool last = c + 1 == P.nch;
+            if (!last) { D_ROWS_LOAD(row0, c + 1) D_W_LOAD(c + 1) }
+            else if (tn < P.ntiles) { D_ROWS_LOAD((int64_t)tn * D_RM, 0) D_W_LOAD(0) }      // (the next tile's resident rows are loaded at the seam)
             if (MODE == 1) {
-                // Loads in the order they are needed (vmcnt retires in order): this chunk's weight fragments first, THEN the prefetch of
-                // the next chunk's rows -- issued the other way round, the first MFMA would wait for the prefetch's HBM latency.
-                const int rb = wave >> 1, cb = wave & 1;
-                const uint4* bp = P.Wq + ((size_t)((c * 2 + cb) * P.S) * 2) * 64 + lane;
-                uint4 wq[16];                                           // S <= 8 steps x (hi, lo)
-#pragma unroll
-                for (int s = 0; s < 8; ++s) {
-                    const int sc_ = min(s, P.S - 1);
-                    wq[2 * s] = bp[(size_t)sc_ * 128]; wq[2 * s + 1] = bp[(size_t)sc_ * 128 + 64];
-                }
-                if (c + 1 < P.nch) chunk_load(row0, c + 1);             // in flight under this chunk's MFMAs
                 // DW[:, chunk] += A^T Y[:, chunk]: (KAp / 32) x 2 tiles, one per wave; k = the 128 tile rows
                 {
                     const int ib = wave >> 1, jb = wave & 1;
                     if (ib * 32 < P.KAp) {
                         const int gq = lane >> 4, hh = gq >> 1, c16 = (gq & 1) * 16;
-                        f32x16 acc = accC;
-#pragma unroll 2
+#pragma unroll 1
                         for (int s = 0; s < D_RM / 16; ++s) {
                             const int r0 = 16 * s + 8 * hh;
                             const bf16x8 ah = d_tr_frag(Rhi, SBR, r0, ib * 32 + c16, lane);
                             const bf16x8 al = d_tr_frag(Rlo, SBR, r0, ib * 32 + c16, lane);
                             const bf16x8 bh = d_tr_frag(Chi, D_SBC, r0, jb * 32 + c16, lane);
                             const bf16x8 bl = d_tr_frag(Clo, D_SBC, r0, jb * 32 + c16, lane);
-                            acc = D_MFMA(al, bh, acc);
-                            acc = D_MFMA(ah, bl, acc);
-                            acc = D_MFMA(ah, bh, acc);
+                            accC = D_MFMA(al, bh, accC);
+                            accC = D_MFMA(ah, bl, accC);
+                            accC = D_MFMA(ah, bh, accC);
                         }
-                        accC = acc;
                     }
                 }
-                DSTAMP(1);
-                // OUT[:, chunk] = A W[:, chunk]: 4 row blocks x 2 column blocks, one per wave; k = KA
+                // OUT[:, chunk] = A W[:, chunk]: 4 row blocks x 2 column blocks, one per wave; k = KA; weight fragments from LDS
                 {
+                    const int rb = wave >> 1, cb = wave & 1;
                     f32x16 acc;
 #pragma unroll
                     for (int r = 0; r < 16; ++r) acc[r] = 0.f;
                     const unsigned char* ah = Rhi + (rb * 32 + (lane & 31)) * SBR + (lane >> 5) * 16;
                     const unsigned char* al = ah + D_RM * SBR;
-#pragma unroll
-                    for (int s = 0; s < 8; ++s) {
-                        if (s < P.S) {
-                            const bf16x8 xh = *reinterpret_cast<const bf16x8*>(ah + s * 32);
-                            const bf16x8 xl = *reinterpret_cast<const bf16x8*>(al + s * 32);
-                            const bf16x8 bh = __builtin_bit_cast(bf16x8, wq[2 * s]), bl = __builtin_bit_cast(bf16x8, wq[2 * s + 1]);
-                            acc = D_MFMA(xl, bh, acc);
-                            acc = D_MFMA(xh, bl, acc);
-                            acc = D_MFMA(xh, bh, acc);
-                        }
+                    const uint4* wl = Wl + (size_t)(cb * P.S) * 128 + lane;
+                    for (int s = 0; s < P.S; ++s) {
+                        const bf16x8 xh = *reinterpret_cast<const bf16x8*>(ah + s * 32);
+                        const bf16x8 xl = *reinterpret_cast<const bf16x8*>(al + s * 32);
+                        const bf16x8 bh = __builtin_bit_cast(bf16x8, wl[s * 128]), bl = __builtin_bit_cast(bf16x8, wl[s * 128 + 64]);
+                        acc = D_MFMA(xl, bh, acc);
+                        acc = D_MFMA(xh, bl, acc);
+                        acc = D_MFMA(xh, bh, acc);
                     }
                     const int col = c * D_CH + cb * 32 + (lane & 31);
                     if (col < P.NO) {
+                        float* const ob = P.OUT + (size_t)(row0 + rb * 32 + 4 * (lane >> 5)) * P.ldo + col;
+                        const int64_t rlim = P.R - (row0 + rb * 32 + 4 * (lane >> 5));           // rows left below this lane's first row
+                        if (P.accumulate) {
 #pragma unroll
-                        for (int r = 0; r < 16; ++r) {
-                            const int64_t row = row0 + rb * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-                            if (row < P.R) {
-                                float* o = P.OUT + (size_t)row * P.ldo + col;
-                                *o = P.accumulate ? *o + acc[r] : acc[r];
-                            }
+                            for (int r = 0; r < 16; ++r) { const int dr = (r & 3) + 8 * (r >> 2); if (dr < rlim) ob[(size_t)dr * P.ldo] += acc[r]; }
+                        } else {
+#pragma unroll
+                            for (int r = 0; r < 16; ++r) { const int dr = (r & 3) + 8 * (r >> 2); if (dr < rlim) ob[(size_t)dr * P.ldo] = acc[r]; }
                         }
                     }
                 }
             } else {
-                // OUT += A[:, chunk] W[chunk, :]: 4 row blocks x ncb column blocks, two per wave; k = 64.  Weight fragments first, then the
-                // prefetch of the next chunk's rows (see MODE 1)
-                uint4 wq[16];
-#pragma unroll
-                for (int u = 0; u < 2; ++u) {
-                    const int cb = min(2 * (wave & 1) + u, P.ncb - 1);
-                    const uint4* bp = P.Wq + ((size_t)((c * P.ncb + cb) * 4) * 2) * 64 + lane;
-#pragma unroll
-                    for (int s = 0; s < 4; ++s) { wq[u * 8 + 2 * s] = bp[(size_t)s * 128]; wq[u * 8 + 2 * s + 1] = bp[(size_t)s * 128 + 64]; }
-                }
-                if (c + 1 < P.nch) chunk_load(row0, c + 1);
+                // OUT += A[:, chunk] W[chunk, :]: 4 row blocks x ncb column blocks, two per wave; k = 64
                 {
                     const int rb = wave >> 1;
                     const unsigned char* ah = Chi + (rb * 32 + (lane & 31)) * D_SBC + (lane >> 5) * 16;
@@ -259,13 +268,13 @@ __global__ __launch_bounds__(DT, 2) void k_dual_gemm(const DualArgs P) {
                     for (int u = 0; u < 2; ++u) {
                         const int cb = 2 * (wave & 1) + u;
                         if (cb < P.ncb) {
+                            const uint4* wl = Wl + (size_t)(cb * 4) * 128 + lane;
                             f32x16 acc = accO[u];
 #pragma unroll
                             for (int s = 0; s < 4; ++s) {
-                                const uint4 wh = wq[u * 8 + 2 * s], wl = wq[u * 8 + 2 * s + 1];
                                 const bf16x8 xh = *reinterpret_cast<const bf16x8*>(ah + s * 32);
                                 const bf16x8 xl = *reinterpret_cast<const bf16x8*>(al + s * 32);
-                                const bf16x8 bh = __builtin_bit_cast(bf16x8, wh), bl = __builtin_bit_cast(bf16x8, wl);
+                                const bf16x8 bh = __builtin_bit_cast(bf16x8, wl[s * 128]), bl = __builtin_bit_cast(bf16x8, wl[s * 128 + 64]);
                                 acc = D_MFMA(xl, bh, acc);
                                 acc = D_MFMA(xh, bl, acc);
                                 acc = D_MFMA(xh, bh, acc);
@@ -279,48 +288,49 @@ __global__ __launch_bounds__(DT, 2) void k_dual_gemm(const DualArgs P) {
                     const int ib = wave >> 2, jb = wave & 3;
                     if (jb * 32 < P.KYp) {
                         const int gq = lane >> 4, hh = gq >> 1, c16 = (gq & 1) * 16;
-                        f32x16 acc = accC;
+#pragma unroll 1
                         for (int s = 0; s < D_RM / 16; ++s) {
                             const int r0 = 16 * s + 8 * hh;
                             const bf16x8 ah = d_tr_frag(Chi, D_SBC, r0, ib * 32 + c16, lane);
                             const bf16x8 al = d_tr_frag(Clo, D_SBC, r0, ib * 32 + c16, lane);
                             const bf16x8 bh = d_tr_frag(Rhi, SBR, r0, jb * 32 + c16, lane);
                             const bf16x8 bl = d_tr_frag(Rlo, SBR, r0, jb * 32 + c16, lane);
-                            acc = D_MFMA(al, bh, acc);
-                            acc = D_MFMA(ah, bl, acc);
-                            acc = D_MFMA(ah, bh, acc);
+                            accC = D_MFMA(al, bh, accC);
+                            accC = D_MFMA(ah, bl, accC);
+                            accC = D_MFMA(ah, bh, accC);
                         }
-                        accC = acc;
+                    }
+                }
+                if (last) {                                      // the tile's OUT rows from the accumulators
+                    const int rb = wave >> 1;
+#pragma unroll
+                    for (int u = 0; u < 2; ++u) {
+                        const int cb = 2 * (wave & 1) + u;
+                        const int col = cb * 32 + (lane & 31);
+                        if (cb < P.ncb && col < P.NO) {
+                            float* const ob = P.OUT + (size_t)(row0 + rb * 32 + 4 * (lane >> 5)) * P.ldo + col;
+                            const int64_t rlim = P.R - (row0 + rb * 32 + 4 * (lane >> 5));
+                            if (P.accumulate) {
+#pragma unroll
+                                for (int r = 0; r < 16; ++r) { const int dr = (r & 3) + 8 * (r >> 2); if (dr < rlim) ob[(size_t)dr * P.ldo] += accO[u][r]; }
+                            } else {
+#pragma unroll
+                                for (int r = 0; r < 16; ++r) { const int dr = (r & 3) + 8 * (r >> 2); if (dr < rlim) ob[(size_t)dr * P.ldo] = accO[u][r]; }
+                            }
+                        }
                     }
                 }
             }
-            DSTAMP(2);
             accW[c] = accC;
-            if (c + 1 < P.nch) chunk_store(dsm + ((c & 1) ? P.offC0 : P.offC1));      // nobody reads the other buffer during this chunk
+            DSTAMP(1);
+            d_barrier();                                        // every wave is done with the chunk planes, the weights (and, at `last`, the resident planes)
+            if (!last) { D_ROWS_STORE() D_W_STORE() }
+            else if (tn < P.ntiles) { D_ROWS_STORE() D_W_STORE() res_fill((int64_t)tn * D_RM); }
             d_barrier();
-            DSTAMP(3);
-            }
-        }
-        if (MODE == 2) {
-            const int rb = wave >> 1;
-#pragma unroll
-            for (int u = 0; u < 2; ++u) {
-                const int cb = 2 * (wave & 1) + u;
-                const int col = cb * 32 + (lane & 31);
-                if (cb < P.ncb && col < P.NO) {
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) {
-                        const int64_t row = row0 + rb * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-                        if (row < P.R) {
-                            float* o = P.OUT + (size_t)row * P.ldo + col;
-                            *o = P.accumulate ? *o + accO[u][r] : accO[u][r];
-                        }
-                    }
-                }
-            }
+            DSTAMP(2);
         }
     }
-    DSTAMP(4);
+    DSTAMP(3);
     // this workgroup's partial of DW: [KAp, ldpart]; MODE 1: rows = KA blocks (wave >> 1), columns = chunk*64 + (wave & 1)*32;
     // MODE 2: rows = chunk*64 + (wave >> 2)*32, columns = (wave & 3)*32
     float* const pw = P.part + (size_t)blockIdx.x * P.KAp * P.ldpart;
@@ -338,7 +348,7 @@ __global__ __launch_bounds__(DT, 2) void k_dual_gemm(const DualArgs P) {
         }
     }
 #ifdef GSAT_FUSED_STAMPS
-    DSTAMP(5);
+    DSTAMP(4);
     if (tid == 0) { for (int i = 0; i < 6; ++i) atomicAdd(&g_dual_stamps[MODE - 1][i], (unsigned long long)dst_[i]); atomicAdd(&g_dual_stamps[MODE - 1][7], 1ull); }
 #endif
 }
@@ -423,9 +433,10 @@ int dual_gemm(hipStream_t stream, int mode, int64_t R, int KA, int KY, int NO, c
     const int prow = mode == 1 ? P.KAp : P.nch * D_CH;           // rows of a partial slab
     const int resw = mode == 1 ? P.KAp : P.KYp;
     P.SBR = resw * 2 + 16;
-    P.offC0 = 2 * D_RM * P.SBR;
-    P.offC1 = P.offC0 + 2 * D_RM * D_SBC;
-    const size_t lds = (size_t)P.offC1 + 2 * D_RM * D_SBC;
+    P.offC0 = 2 * D_RM * P.SBR;                                  // chunk planes
+    P.offC1 = P.offC0 + 2 * D_RM * D_SBC;                        // the chunk's weight fragments: ncb * S * 2 * 64 uint4 (<= 32 KB)
+    const size_t lds = (size_t)P.offC1 + (size_t)P.ncb * P.S * 2 * 64 * 16;
+    GSAT_REQUIRE(P.ncb * P.S * 2 * 64 <= 4 * DT, GSAT_ERR_UNSUPPORTED, "dual_gemm: weight chunk too large");
     P.ntiles = (int)ceil_div(R, D_RM);
     char* w = static_cast<char*>(ws);
     uint4* Wq = reinterpret_cast<uint4*>(w); w += align_up((size_t)P.nch * P.ncb * P.S * 2 * 64 * 16, 256);

@@ -35,7 +35,7 @@ def main(wl="c3"):
             v = d[mode * 8:mode * 8 + 8]
             n = max(v[7], 1)
             print(f"dual MODE {mode + 1}: workgroup-runs {v[7]}")
-            for nme, x in zip(["0 resident + chunk 0", "1 weights + DW product", "2 row product + stores", "3 chunk store + barrier", "4 tile tail", "5 partials"], v[:6]):
+            for nme, x in zip(["0 prologue fill", "1 chunk: prefetch issue + MFMAs + OUT stores", "2 chunk: barrier + LDS stores + barrier", "3 -", "4 partials", "5 -"], v[:6]):
                 print(f"   {nme:26s} {x / n:10.0f} cycles per workgroup-run")
         return
     lib.gsat_debug_bwd_counters.restype = ctypes.POINTER(ctypes.c_int * 64)
