@@ -367,10 +367,21 @@ __global__ __launch_bounds__(FT, 2) void k_attn_fused_fwd(const FusedArgs A) {
         // =========================== big graph, pass 0: P (| Q) of all its nodes -> global ===========================
         // (small tiles run the same GEMM1 code on their single slab inside the chunk loop below)
         auto load_x = [&](int x0, int nx) {            // rows [x0, x0 + nx) of emb -> X, zero-filled to a multiple of 32 rows
+            // four 16-byte loads per thread in flight, issued unconditionally (row clamped, zeroed at the LDS store): a load under
+            // `r < nx ? load : 0` compiles to a branch that waits for every load before the next one is issued
             const int fill = min((nx + 31) & ~31, EDGE ? 64 : RM);
-            for (int i = tid; i < fill * H4; i += FT) {
-                const int r = i / H4, q = i - r * H4;
-                st4(X + r * LDX + 4 * q, r < nx ? ld4(A.emb + (size_t)(x0 + r) * H + 4 * q) : f4zero());
+            for (int i0 = tid; i0 < fill * H4; i0 += 4 * FT) {
+                float4 v[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const int i = min(i0 + u * FT, fill * H4 - 1), r = i / H4, q = i - r * H4;
+                    v[u] = ld4(A.emb + (size_t)(x0 + min(r, nx - 1)) * H + 4 * q);
+                }
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const int i = i0 + u * FT, r = i / H4, q = i - r * H4;
+                    if (i < fill * H4) st4(X + r * LDX + 4 * q, r < nx ? v[u] : f4zero());
+                }
             }
         };
         // layer 1 of chunk kc on the rows in X -> LDS without the bias: node mode T[row][CH], edge mode U[node][P half | Q half]
