@@ -15,6 +15,7 @@ struct FusedGeom {
     int LDX, LDU, LDT, LDH, SW;     // LDS row strides (floats) and the width of a statistics row
     int offU, offT, offS, offMeta;  // LDS offsets (floats)
     int lds_bytes;
+    int x6;                         // layer products as split-bf16 x 6 (hi / mid / lo planes, six MFMAs per 16 k) instead of fp32 MFMA
 };
 
 // a tile of whole graphs: MLP rows [row0, row0 + nrows) of graphs [g0, g0 + ng), their nodes [node0, node0 + nnodes); flags & 1: one graph

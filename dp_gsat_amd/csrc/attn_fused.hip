@@ -64,8 +64,8 @@ bool fused_geometry(int H, int C1, int C2, bool edge, FusedGeom* out) {
 size_t fused_ws_bytes(const FusedGeom& g, int64_t G) {
     size_t b = 256;                                                                 // counters
     b += align_up((size_t)(G + 1 + (G + 63) / 64 * 64) * sizeof(FTile), 256);       // compact tile list + the planner's sparse scratch
-    b += align_up((size_t)g.NCH * 4 * g.S1 * 64 * 16, 256);                          // Wp1
-    b += align_up((size_t)g.NCH * g.NCB2 * g.S2 * 64 * 16, 256);                     // Wp2
+    b += align_up((size_t)g.NCH * 4 * g.S1 * 64 * 24, 256);                          // Wp1 (fp32 fragments, or 3 bf16 planes: 1.5 x)
+    b += align_up((size_t)g.NCH * g.NCB2 * g.S2 * 64 * 24, 256);                     // Wp2
     return b;
 }
 
@@ -176,8 +176,52 @@ __global__ __launch_bounds__(PLAN_T) void k_attn_prep(const float* __restrict__ 
         plan_tiles_block(seg_ptr, node_ptr, G, g.RM, g.RX, tiles, counters);
         return;
     }
-    const int64_t n1 = (int64_t)g.NCH * 4 * g.S1 * 64, n2 = (int64_t)g.NCH * g.NCB2 * g.S2 * 64;
     const int K1 = edge ? 2 * g.H : g.H;
+    if (g.x6) {
+        // split-bf16 x 6: three planes per fragment (top 16 bits of x, of x - hi, of x - hi - mid: an exact 8 + 8 + 8-bit decomposition),
+        // Wx[((stream*S + s)*3 + plane)*64 + lane] = 8 bf16: k = 16 s + 8 (lane >> 5) + j of column (lane & 31)
+        const int S1x = g.H / 16, S2x = g.CH / 16;
+        const int64_t m1 = (int64_t)g.NCH * 4 * S1x * 3 * 64, m2 = (int64_t)g.NCH * g.NCB2 * S2x * 3 * 64;
+        uint4* const X1 = reinterpret_cast<uint4*>(Wp1);
+        uint4* const X2 = reinterpret_cast<uint4*>(Wp2);
+        for (int64_t i = (int64_t)(blockIdx.x - 1) * PLAN_T + threadIdx.x; i < m1 + m2; i += (int64_t)(gridDim.x - 1) * PLAN_T) {
+            const bool first = i < m1;
+            const int64_t j = first ? i : i - m1;
+            const int lane = (int)(j & 63), c = lane & 31, h = lane >> 5;
+            const int plane = (int)((j >> 6) % 3);
+            const int64_t q = (j >> 6) / 3;
+            const float* src = nullptr;
+            if (first) {
+                const int s = (int)(q % S1x), st = (int)(q / S1x), cb = st & 3, kc = st >> 2;
+                const int k = 16 * s + 8 * h;
+                int col, koff = 0;
+                if (edge) { col = kc * 64 + (cb & 1) * 32 + c; koff = (cb >> 1) * g.H; }
+                else col = kc * 128 + cb * 32 + c;
+                if (col < g.C1) src = W1 + (size_t)col * K1 + koff + k;
+            } else {
+                const int s = (int)(q % S2x), st = (int)(q / S2x), cb = st % g.NCB2, kc = st / g.NCB2;
+                const int col = cb * 32 + c, k = kc * g.CH + 16 * s + 8 * h;
+                if (col < g.C2 && k < g.C1) src = W2 + (size_t)col * g.C1 + k;          // C1 % 8 may be 4: the tail is zero-filled below
+            }
+            unsigned w[4] = {0u, 0u, 0u, 0u};
+            if (src) {
+                float v[8];
+                const int kk = first ? 0 : (int)(((j >> 6) / 3 / S2x) / g.NCB2) * g.CH + 16 * (int)(((j >> 6) / 3) % S2x) + 8 * h;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) v[e] = (first || kk + e < g.C1) ? src[e] : 0.f;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    unsigned u = __builtin_bit_cast(unsigned, v[e]);
+                    if (plane >= 1) { const float r1 = v[e] - __builtin_bit_cast(float, u & 0xFFFF0000u); u = __builtin_bit_cast(unsigned, r1);
+                        if (plane == 2) { const float r2 = r1 - __builtin_bit_cast(float, u & 0xFFFF0000u); u = __builtin_bit_cast(unsigned, r2); } }
+                    w[e >> 1] |= (u >> 16) << (16 * (e & 1));
+                }
+            }
+            (first ? X1 : X2)[j] = make_uint4(w[0], w[1], w[2], w[3]);
+        }
+        return;
+    }
+    const int64_t n1 = (int64_t)g.NCH * 4 * g.S1 * 64, n2 = (int64_t)g.NCH * g.NCB2 * g.S2 * 64;
     for (int64_t i = (int64_t)(blockIdx.x - 1) * PLAN_T + threadIdx.x; i < n1 + n2; i += (int64_t)(gridDim.x - 1) * PLAN_T) {
         float4 v = f4zero();
         if (i < n1) {
@@ -230,6 +274,66 @@ __device__ __forceinline__ void mma_run(f32x16& acc0, f32x16& acc1, const float*
                 if (NA > 1) acc1 = GSAT_MFMA(x1.z, w.z, acc1);
                 acc0 = GSAT_MFMA(x0.w, w.w, acc0);
                 if (NA > 1) acc1 = GSAT_MFMA(x1.w, w.w, acc1);
+            }
+        }
+    }
+}
+
+typedef __attribute__((ext_vector_type(8))) __bf16 fbf16x8;
+typedef __attribute__((ext_vector_type(4))) unsigned fu32x4;
+#define GSAT_MFMA_B(a, b, c) __builtin_amdgcn_mfma_f32_32x32x16_bf16((a), (b), (c), 0, 0, 0)
+
+// x (8 fp32) -> three bf16 fragments whose sum is x exactly: top 16 bits of x, of x - hi, of x - hi - mid (truncation keeps every
+// remainder exactly representable, so 8 + 8 + 8 mantissa bits are covered).  ~4.5 VALU ops per element.
+__device__ __forceinline__ void split3(const float4 lo4, const float4 hi4, fbf16x8& p0, fbf16x8& p1, fbf16x8& p2) {
+    const float x[8] = {lo4.x, lo4.y, lo4.z, lo4.w, hi4.x, hi4.y, hi4.z, hi4.w};
+    fu32x4 a, b, c;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        const unsigned u0 = __builtin_bit_cast(unsigned, x[2 * e]), u1 = __builtin_bit_cast(unsigned, x[2 * e + 1]);
+        const float r0 = x[2 * e] - __builtin_bit_cast(float, u0 & 0xFFFF0000u), r1 = x[2 * e + 1] - __builtin_bit_cast(float, u1 & 0xFFFF0000u);
+        const unsigned v0 = __builtin_bit_cast(unsigned, r0), v1 = __builtin_bit_cast(unsigned, r1);
+        const float s0 = r0 - __builtin_bit_cast(float, v0 & 0xFFFF0000u), s1 = r1 - __builtin_bit_cast(float, v1 & 0xFFFF0000u);
+        a[e] = __builtin_amdgcn_perm(u1, u0, 0x07060302u);
+        b[e] = __builtin_amdgcn_perm(v1, v0, 0x07060302u);
+        c[e] = __builtin_amdgcn_perm(__builtin_bit_cast(unsigned, s1), __builtin_bit_cast(unsigned, s0), 0x07060302u);
+    }
+    p0 = __builtin_bit_cast(fbf16x8, a); p1 = __builtin_bit_cast(fbf16x8, b); p2 = __builtin_bit_cast(fbf16x8, c);
+}
+
+// the same products on the bf16 matrix pipe: A (fp32 rows in LDS, this lane's row and its 8-k half applied) split in registers, B as three
+// pre-split planes in the fragment stream; per 16 k six MFMAs (x0 y0 + x0 y1 + x1 y0 + x0 y2 + x2 y0 + x1 y1, small terms first) = 192
+// cycles against 512 for eight fp32 MFMAs; the dropped terms are <= 2^-24 of |x||y|
+template <int NA>
+__device__ __forceinline__ void mma_run_x6(f32x16& acc0, f32x16& acc1, const float* a0, const float* a1, const uint4* __restrict__ bp, const int S) {
+    uint4 b[3][3];
+#pragma unroll
+    for (int p = 0; p < 3; ++p) { b[0][p] = bp[p * 64]; b[1][p] = bp[(3 * min(1, S - 1) + p) * 64]; }
+    for (int s = 0; s < S; s += 3) {
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {
+            if (s + j < S) {
+                const int sn = min(s + j + 2, S - 1);
+#pragma unroll
+                for (int p = 0; p < 3; ++p) b[(j + 2) % 3][p] = bp[(3 * sn + p) * 64];
+                const fbf16x8 y0 = __builtin_bit_cast(fbf16x8, b[j][0]), y1 = __builtin_bit_cast(fbf16x8, b[j][1]), y2 = __builtin_bit_cast(fbf16x8, b[j][2]);
+                fbf16x8 x0, x1, x2;
+                split3(ld4(a0 + 16 * (s + j)), ld4(a0 + 16 * (s + j) + 4), x0, x1, x2);
+                acc0 = GSAT_MFMA_B(x2, y0, acc0);
+                acc0 = GSAT_MFMA_B(x0, y2, acc0);
+                acc0 = GSAT_MFMA_B(x1, y1, acc0);
+                acc0 = GSAT_MFMA_B(x1, y0, acc0);
+                acc0 = GSAT_MFMA_B(x0, y1, acc0);
+                acc0 = GSAT_MFMA_B(x0, y0, acc0);
+                if (NA > 1) {
+                    split3(ld4(a1 + 16 * (s + j)), ld4(a1 + 16 * (s + j) + 4), x0, x1, x2);
+                    acc1 = GSAT_MFMA_B(x2, y0, acc1);
+                    acc1 = GSAT_MFMA_B(x0, y2, acc1);
+                    acc1 = GSAT_MFMA_B(x1, y1, acc1);
+                    acc1 = GSAT_MFMA_B(x1, y0, acc1);
+                    acc1 = GSAT_MFMA_B(x0, y1, acc1);
+                    acc1 = GSAT_MFMA_B(x0, y0, acc1);
+                }
             }
         }
     }
@@ -309,7 +413,7 @@ struct FusedArgs {
     FusedGeom g;
 };
 
-template <bool EDGE, int NRB, int NCB2W>
+template <bool EDGE, int NRB, int NCB2W, bool X6>
 __global__ __launch_bounds__(FT, 2) void k_attn_fused_fwd(const FusedArgs A) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const FusedGeom& g = A.g;
@@ -389,10 +493,12 @@ __global__ __launch_bounds__(FT, 2) void k_attn_fused_fwd(const FusedArgs A) {
             f32x16 acc0, acc1;
             acc_zero(acc0); acc_zero(acc1);
             const float4* bp = A.Wp1 + ((size_t)(kc * 4 + cw) * g.S1) * 64 + lane;
+            const uint4* bx = reinterpret_cast<const uint4*>(A.Wp1) + ((size_t)(kc * 4 + cw) * (H / 16)) * 192 + lane;       // split-bf16 stream
             if (EDGE) {
                 const int rb = rw;
                 if (rb * 32 < nx) {
-                    mma_run<1>(acc0, acc1, X + (rb * 32 + c) * LDX + h * (H / 2), nullptr, bp, g.S1);
+                    if (X6) mma_run_x6<1>(acc0, acc1, X + (rb * 32 + c) * LDX + 8 * h, nullptr, bx, H / 16);
+                    else mma_run<1>(acc0, acc1, X + (rb * 32 + c) * LDX + h * (H / 2), nullptr, bp, g.S1);
                     float* const o = U + (rb * 32 + 4 * h) * LDU + cw * 32 + c;
 #pragma unroll
                     for (int r = 0; r < 16; ++r) o[((r & 3) + 8 * (r >> 2)) * LDU] = acc0[r];
@@ -401,9 +507,15 @@ __global__ __launch_bounds__(FT, 2) void k_attn_fused_fwd(const FusedArgs A) {
                 const int rb0 = rw * NRB;
                 const int na = min(NRB, (nx - rb0 * 32 + 31) / 32);
                 if (na > 0) {
+                    if (X6) {
+                        const float* a0 = X + (rb0 * 32 + c) * LDX + 8 * h;
+                        if (NRB > 1 && na > 1) mma_run_x6<2>(acc0, acc1, a0, a0 + 32 * LDX, bx, H / 16);
+                        else mma_run_x6<1>(acc0, acc1, a0, nullptr, bx, H / 16);
+                    } else {
                     const float* a0 = X + (rb0 * 32 + c) * LDX + h * (H / 2);
                     if (NRB > 1 && na > 1) mma_run<2>(acc0, acc1, a0, a0 + 32 * LDX, bp, g.S1);
                     else mma_run<1>(acc0, acc1, a0, nullptr, bp, g.S1);
+                    }
                     float* const o = T + (rb0 * 32 + 4 * h) * LDT + cw * 32 + c;
 #pragma unroll
                     for (int r = 0; r < 16; ++r) o[((r & 3) + 8 * (r >> 2)) * LDT] = acc0[r];
@@ -609,14 +721,20 @@ __global__ __launch_bounds__(FT, 2) void k_attn_fused_fwd(const FusedArgs A) {
                     const int rb0 = rw * NRB;
                     const int na = min(NRB, (nr - rb0 * 32 + 31) / 32);
                     if (na > 0) {
-                        const float* a0 = T + (rb0 * 32 + c) * LDT + h * (CH / 2);
+                        const float* a0 = T + (rb0 * 32 + c) * LDT + (X6 ? 8 * h : h * (CH / 2));
 #pragma unroll
                         for (int j = 0; j < NCB2W; ++j) {
                             const int cb2 = cw + 4 * j;
                             if (cb2 < g.NCB2) {
+                                if (X6) {
+                                    const uint4* bx = reinterpret_cast<const uint4*>(A.Wp2) + ((size_t)(kc * g.NCB2 + cb2) * (CH / 16)) * 192 + lane;
+                                    if (NRB > 1 && na > 1) mma_run_x6<2>(acc2[j][0], acc2[j][NRB - 1], a0, a0 + 32 * LDT, bx, CH / 16);
+                                    else mma_run_x6<1>(acc2[j][0], acc2[j][NRB - 1], a0, nullptr, bx, CH / 16);
+                                } else {
                                 const float4* bp = A.Wp2 + ((size_t)(kc * g.NCB2 + cb2) * S2) * 64 + lane;
                                 if (NRB > 1 && na > 1) mma_run<2>(acc2[j][0], acc2[j][NRB - 1], a0, a0 + 32 * LDT, bp, S2);
                                 else mma_run<1>(acc2[j][0], acc2[j][NRB - 1], a0, nullptr, bp, S2);
+                                }
                             }
                         }
                     }
@@ -755,15 +873,15 @@ __global__ __launch_bounds__(FT, 2) void k_attn_fused_fwd(const FusedArgs A) {
 #endif
 }
 
-template <bool EDGE, int NRB, int NCB2W>
+template <bool EDGE, int NRB, int NCB2W, bool X6 = false>
 static int launch_fused(hipStream_t stream, const FusedArgs& fa, int grid) {
     static size_t allowed = 64 * 1024;
     const size_t lds = (size_t)fa.g.lds_bytes;
     if (lds > allowed) {
-        GSAT_CHECK_HIP(hipFuncSetAttribute((const void*)k_attn_fused_fwd<EDGE, NRB, NCB2W>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        GSAT_CHECK_HIP(hipFuncSetAttribute((const void*)k_attn_fused_fwd<EDGE, NRB, NCB2W, X6>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         allowed = lds;
     }
-    k_attn_fused_fwd<EDGE, NRB, NCB2W><<<grid, FT, lds, stream>>>(fa);
+    k_attn_fused_fwd<EDGE, NRB, NCB2W, X6><<<grid, FT, lds, stream>>>(fa);
     GSAT_LAUNCH_CHECK();
     return GSAT_OK;
 }
@@ -786,6 +904,10 @@ bool attn_fused_eligible(const gsat_attn_args* a, FusedGeom* g) {
     if (!a->edge_mode && a->seg_order) return false;
     if (a->edge_mode && !a->node_ptr) return false;
     if (!fused_geometry(a->H, a->C1, a->C2, a->edge_mode != 0, g)) return false;
+    {   // split-bf16 x 6 products (GSAT_ATTN_FUSED_X6=0: exact fp32 MFMA): the common tile shape only, K a multiple of 16
+        const char* ex = getenv("GSAT_ATTN_FUSED_X6");
+        g->x6 = (!(ex && atoi(ex) == 0) && a->H % 16 == 0 && g->NRB == 2 && g->NCB2 <= 4) ? 1 : 0;
+    }
     // batches of huge graphs (C5: ~10^5 rows per graph) belong to the streaming pipeline; an occasional large graph is walked in slabs here
     if (a->M > a->G * (int64_t)(2 * g->RM)) return false;
     return true;
@@ -798,7 +920,7 @@ int attn_fused_fwd(hipStream_t stream, const gsat_attn_args* a, const FusedGeom&
     char* w = static_cast<char*>(a->fwd_workspace);
     int* counters = reinterpret_cast<int*>(w); w += 256;
     FTile* tiles = reinterpret_cast<FTile*>(w); w += align_up((size_t)(a->G + 1 + (a->G + 63) / 64 * 64) * sizeof(FTile), 256);
-    float4* Wp1 = reinterpret_cast<float4*>(w); w += align_up((size_t)g.NCH * 4 * g.S1 * 64 * 16, 256);
+    float4* Wp1 = reinterpret_cast<float4*>(w); w += align_up((size_t)g.NCH * 4 * g.S1 * 64 * 24, 256);
     float4* Wp2 = reinterpret_cast<float4*>(w);
     const int64_t nflt4 = (int64_t)g.NCH * 4 * g.S1 * 64 + (int64_t)g.NCH * g.NCB2 * g.S2 * 64;
     const int pack_blocks = (int)std::min<int64_t>(ceil_div(nflt4, PLAN_T), 512);
@@ -828,6 +950,7 @@ int attn_fused_fwd(hipStream_t stream, const gsat_attn_args* a, const FusedGeom&
     const bool e = a->edge_mode != 0;
     const int ncbw = g.NCB2 > 4 ? 2 : 1;
 #define GO(E, R, W) return launch_fused<E, R, W>(stream, fa, grid)
+    if (g.x6) { if (e) return launch_fused<true, 2, 1, true>(stream, fa, grid); return launch_fused<false, 2, 1, true>(stream, fa, grid); }
     if (e) { if (g.NRB == 2) { if (ncbw == 2) GO(true, 2, 2); GO(true, 2, 1); } if (ncbw == 2) GO(true, 1, 2); GO(true, 1, 1); }
     if (g.NRB == 2) { if (ncbw == 2) GO(false, 2, 2); GO(false, 2, 1); }
     if (ncbw == 2) GO(false, 1, 2);
