@@ -558,11 +558,19 @@ def main():
     ms = dt / args.steps * 1e3
     value = e_total / (dt / args.steps) / 1e6
 
-    # the same step with the extractor's four backward products on exact fp32 MFMA instead of split-bf16 (GSAT_ATTN_BWD_SPLIT=0),
-    # measured in the same process so that the line says what the default costs / buys
+    from dp_gsat_amd.ops import ExtractorAttention
+    fwd_kind = ExtractorAttention.last_forward_kind                  # what the timed steps ran (gsat_attn_fwd_kind)
+    FWD_PRECISION = {0: "extractor forward: staged kernels, layer products (P|Q, h2) exact fp32 MFMA",
+                     1: "extractor forward: one-launch kernel (whole graphs per workgroup), layer products exact fp32 MFMA",
+                     2: "extractor forward: one-launch kernel (whole graphs per workgroup), layer products split-bf16 x6 (operands as three bf16 planes, six "
+                        "bf16 MFMA per 16 k, fp32 accumulate: rel. error ~1e-6, fp32-GEMM level)"}
+    # the same step with every extractor product on exact fp32 MFMA (GSAT_ATTN_BWD_SPLIT=0, staged forward), measured in the same
+    # process so that the line says what the default costs / buys
     value_exact = ms_exact = None
     if world == 1 and not distributed and not args.no_exact_rerun:
         os.environ["GSAT_ATTN_BWD_SPLIT"] = "0"
+        fused_env = os.environ.get("GSAT_ATTN_FUSED")
+        os.environ["GSAT_ATTN_FUSED"] = "0"            # the staged forward: exact fp32 MFMA
         try:
             step_exact = captured(hot.step) if args.graph else hot.step
             dte = timed(step_exact, args.steps, max(args.warmup // 2, 2), dev, False)
@@ -570,6 +578,10 @@ def main():
             value_exact = e_total / (dte / args.steps) / 1e6
         finally:
             del os.environ["GSAT_ATTN_BWD_SPLIT"]
+            if fused_env is None:
+                del os.environ["GSAT_ATTN_FUSED"]
+            else:
+                os.environ["GSAT_ATTN_FUSED"] = fused_env
 
     full = None
     if not args.no_full_step:
@@ -585,7 +597,7 @@ def main():
         fsteps = max(args.steps // 2, 3)
         full = dict(value=round(e_total / (fdt / fsteps) / 1e6, 3), unit="million edges/s", ms_per_step=round(fdt / fsteps * 1e3, 3),
                     what="whole GSAT training step: 2 backbone passes + extractor + losses + backward + Adam (+ all-reduce)", hipgraph=full_graph,
-                    gemm_precision="extractor forward products: fp32 MFMA (exact); extractor backward products (da1, demb, dW1, dW2) and backbone "
+                    gemm_precision=FWD_PRECISION[ExtractorAttention.last_forward_kind] + "; extractor backward products (da1, demb, dW1, dW2) and backbone "
                                    "Linear layers >= 2 GFLOP (forward, dx, dW): bf16x3 (split-bf16 hi*hi + hi*lo + lo*hi, fp32 accumulate, rel. error ~1e-5); "
                                    "smaller Linear layers: library fp32 GEMM")
 
@@ -605,7 +617,7 @@ def main():
             "metric": "million edges/s (attn+sample+aggregate fwd+bwd)", "value": round(value, 3), "unit": "million edges/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms, 4),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "gemm_precision": "timed region: extractor forward products (P|Q, h2) exact fp32 MFMA; extractor backward products (da1, demb, dW1, dW2) "
+            "gemm_precision": "timed region: " + FWD_PRECISION[fwd_kind] + "; extractor backward products (da1, demb, dW1, dW2) "
                               "split-bf16 x3 (hi*hi + hi*lo + lo*hi on bf16 MFMA, fp32 accumulate, rel. error ~1e-5 of each gradient's scale); "
                               "aggregation kernels fp32 VALU; no other GEMM in scope A",
             "value_fp32_exact": None if value_exact is None else round(value_exact, 3),

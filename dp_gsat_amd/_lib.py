@@ -62,6 +62,7 @@ SIGNATURES = {
     "gsat_gemm_f32": (INT, [INT, INT, I64, I64, I64, P, I64, P, I64, P, I64, P, INT, P, SZ, P]),
     "gsat_gemm_bf16x3": (INT, [INT, INT, I64, I64, I64, P, I64, P, I64, P, I64, P, INT, P, SZ, P]),
     "gsat_attn_fwd_workspace_bytes": (SZ, [P]),
+    "gsat_attn_fwd_kind": (I32, [P]),
     "gsat_attn_bwd_workspace_bytes": (SZ, [P]),
     "gsat_attn_fwd": (INT, [P, P]),
     "gsat_attn_bwd": (INT, [P, P, P]),

@@ -830,6 +830,13 @@ size_t gsat_attn_fwd_workspace_bytes(const gsat_attn_args* a) {
     return Z > 1 ? (size_t)a->G * Z * std::max(a->C1, a->C2) * sizeof(float) : 0;
 }
 
+int gsat_attn_fwd_kind(const gsat_attn_args* a) {
+    if (!a) return 0;
+    FusedGeom fg;
+    if (!attn_fused_eligible(a, &fg)) return 0;
+    return fg.x6 ? 2 : 1;
+}
+
 size_t gsat_attn_bwd_workspace_bytes(const gsat_attn_args* a) {
     if (!a) return 0;
     const size_t M = (size_t)a->M, N = (size_t)a->N, G = (size_t)a->G, C1 = a->C1, C2 = a->C2;

@@ -382,8 +382,20 @@ __device__ __forceinline__ void column_stats(const float* col, const int LD, flo
     float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
 #pragma unroll
     for (int j = 0; j < RC; j += 4) { s0 += v[j]; s1 += v[j + 1]; s2 += v[j + 2]; s3 += v[j + 3]; }
-    float s = (s0 + s1) + (s2 + s3);
-    for (int r = b + RC; r < e; ++r) s += col[r * LD] + bias;
+    float s;
+    // longer graphs (edge mode: ~2 edges per atom): the rest in batches of 16 loads, again unconditional and all in flight
+    const int n = e - b;
+    for (int r0 = RC; r0 < n; r0 += 16) {
+        float w[16];
+#pragma unroll
+        for (int j = 0; j < 16; ++j) w[j] = p[min((r0 + j) * LD, lastoff)];
+#pragma unroll
+        for (int j = 0; j < 16; j += 4) {
+            s0 += (r0 + j < n) ? w[j] + bias : 0.f; s1 += (r0 + j + 1 < n) ? w[j + 1] + bias : 0.f;
+            s2 += (r0 + j + 2 < n) ? w[j + 2] + bias : 0.f; s3 += (r0 + j + 3 < n) ? w[j + 3] + bias : 0.f;
+        }
+    }
+    s = (s0 + s1) + (s2 + s3);
     const float mu = s * inv_n;
     float q0 = 0.f, q1 = 0.f, q2 = 0.f, q3 = 0.f;
 #pragma unroll
@@ -392,8 +404,18 @@ __device__ __forceinline__ void column_stats(const float* col, const int LD, flo
         const float d2 = (b + j + 2 < e) ? v[j + 2] - mu : 0.f, d3 = (b + j + 3 < e) ? v[j + 3] - mu : 0.f;
         q0 = fmaf(d0, d0, q0); q1 = fmaf(d1, d1, q1); q2 = fmaf(d2, d2, q2); q3 = fmaf(d3, d3, q3);
     }
-    float q = (q0 + q1) + (q2 + q3);
-    for (int r = b + RC; r < e; ++r) { const float d = (col[r * LD] + bias) - mu; q = fmaf(d, d, q); }
+    for (int r0 = RC; r0 < n; r0 += 16) {
+        float w[16];
+#pragma unroll
+        for (int j = 0; j < 16; ++j) w[j] = p[min((r0 + j) * LD, lastoff)];
+#pragma unroll
+        for (int j = 0; j < 16; j += 4) {
+            const float d0 = (r0 + j < n) ? (w[j] + bias) - mu : 0.f, d1 = (r0 + j + 1 < n) ? (w[j + 1] + bias) - mu : 0.f;
+            const float d2 = (r0 + j + 2 < n) ? (w[j + 2] + bias) - mu : 0.f, d3 = (r0 + j + 3 < n) ? (w[j + 3] + bias) - mu : 0.f;
+            q0 = fmaf(d0, d0, q0); q1 = fmaf(d1, d1, q1); q2 = fmaf(d2, d2, q2); q3 = fmaf(d3, d3, q3);
+        }
+    }
+    const float q = (q0 + q1) + (q2 + q3);
     *mean = mu;
     *rstd = 1.f / sqrtf(q * inv_n + F_EPS);
 }
@@ -895,11 +917,13 @@ int attn_plan_launch(hipStream_t stream, const int32_t* seg_ptr, const int32_t* 
 }
 
 bool attn_fused_eligible(const gsat_attn_args* a, FusedGeom* g) {
-    // Default: the staged pipeline.  Measured on MI355X (profiles/r03_summary.md): with exact-fp32 MFMA the one-launch forward ties it at C3
-    // (148 + prep vs ~155 us) and loses on the small / edge-mode batches (few tiles, serial phases per tile), so it is opt-in:
-    // args->fused = 1 or GSAT_ATTN_FUSED=1.
+    // Policy (measured on MI355X, profiles/r03_summary.md).  args->fused / GSAT_ATTN_FUSED: 1 = take the one-launch forward whenever the
+    // shapes allow it, -1 / "0" = never, 0 / unset = automatic: node mode with the split-bf16 x 6 products on a batch of at least 32768
+    // rows (C3: 0.935 vs 0.949 ms per step).  Small batches and edge-mode batches stay on the staged pipeline: with one workgroup per CU
+    // and barrier-separated phases a launch of few tiles loses (C1 / C2 / C4).
     const char* env = getenv("GSAT_ATTN_FUSED");                   // read per call: tests flip it inside one process
-    if (a->fused < 0 || (a->fused == 0 && !(env && atoi(env) != 0))) return false;
+    const int want = a->fused != 0 ? a->fused : (env ? (atoi(env) != 0 ? 1 : -1) : 0);
+    if (want < 0) return false;
     if (a->M <= 0 || a->G <= 0 || a->G > (int64_t)PLAN_MAX_SB * 64) return false;
     if (!a->edge_mode && a->seg_order) return false;
     if (a->edge_mode && !a->node_ptr) return false;
@@ -910,6 +934,7 @@ bool attn_fused_eligible(const gsat_attn_args* a, FusedGeom* g) {
     }
     // batches of huge graphs (C5: ~10^5 rows per graph) belong to the streaming pipeline; an occasional large graph is walked in slabs here
     if (a->M > a->G * (int64_t)(2 * g->RM)) return false;
+    if (want == 0 && (a->edge_mode || !g->x6 || a->M < 32768)) return false;
     return true;
 }
 

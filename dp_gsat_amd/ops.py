@@ -226,7 +226,7 @@ def _attn_args(emb, params, index, segments, edge_mode, training, p, seed, mask1
     a.P, a.Q, a.a1, a.h2, a.stats, a.logits, a.att = ptr(P), ptr(Q), ptr(a1), ptr(h2), ptr(stats), ptr(logits), ptr(att)
     a.seed_dev = ptr(seed_dev)
     a.noise_philox = int(bool(noise_philox) and u is None)
-    a.fused = 0              # library default (staged pipeline; GSAT_ATTN_FUSED=1 opts into the one-launch forward)
+    a.fused = 0              # library policy: one-launch forward for large node-mode batches (GSAT_ATTN_FUSED=1 / 0 forces / forbids it)
     a.node_ptr = ptr(segments.node_ptr)
     return a
 
@@ -236,6 +236,8 @@ class ExtractorAttention(torch.autograd.Function):
 
     replaces: ExtractorMLP.forward + MLP/BatchSequential/InstanceNorm + GSAT.sampling
     (example/gsat.py:94-103,131-139; src/utils/get_model.py:47-68; src/run_gsat.py:877-927)."""
+
+    last_forward_kind = 0        # what the library chose for the latest forward (gsat_attn_fwd_kind): for logs and the bench line
 
     @staticmethod
     def forward(ctx, emb, W1, b1, W2, b2, W3, b3, index, segments, edge_mode, training, p, seed, mask1, mask2, u, seed_dev=None, noise_philox=False):
@@ -270,6 +272,7 @@ class ExtractorAttention(torch.autograd.Function):
         args = _attn_args(emb, params, index, segments, edge_mode, training, p, seed, mask1, mask2, u, bufs, seed_dev, noise_philox)
         from ._lib import load
         fws_bytes = int(load().gsat_attn_fwd_workspace_bytes(ctypes.byref(args)))
+        ExtractorAttention.last_forward_kind = int(load().gsat_attn_fwd_kind(ctypes.byref(args)))      # 0 staged / 1 fused fp32 / 2 fused split-bf16 x 6
         if fws_bytes:
             fws = torch.empty(fws_bytes, dtype=torch.uint8, device=dev)
             args.fwd_workspace, args.fwd_workspace_bytes = ptr(fws), fws_bytes

@@ -402,8 +402,9 @@ typedef struct gsat_attn_args {
     const uint64_t* seed_dev;  /* nullable DEVICE word overriding `seed` (hipGraph replays: new dropout mask per replay) */
     int32_t noise_philox;      /* != 0 with `training` and u == NULL: draw the concrete sampler's u in the kernel (Philox stream 4 of
                                   `seed`, row-keyed) instead of reading a tensor -- the reference's uniform_ launch (example/gsat.py:96) */
-    int32_t fused;             /* 1: take the fused one-launch forward (whole graphs per workgroup, attn_fused.hip) when the shapes allow it;
-                                  0: library default (the staged pipeline unless GSAT_ATTN_FUSED=1 is set); -1: never */
+    int32_t fused;             /* one-launch forward (whole graphs per workgroup, attn_fused.hip): 1 = whenever the shapes allow it, -1 = never,
+                                  0 = automatic (GSAT_ATTN_FUSED=1 / 0 overrides): node mode, H % 16 == 0, M >= 32768 rows; its layer products
+                                  are split-bf16 x 6 on the bf16 matrix pipe (fp32-level accuracy; GSAT_ATTN_FUSED_X6=0: exact fp32 MFMA) */
     const int32_t* node_ptr;   /* [G+1] node segments of the batch; edge mode needs it for the fused forward (NULL: staged pipeline) */
 } gsat_attn_args;
 
@@ -422,6 +423,9 @@ typedef struct gsat_attn_grads {
 } gsat_attn_grads;
 
 size_t gsat_attn_fwd_workspace_bytes(const gsat_attn_args* args);
+/* which forward gsat_attn_fwd will run for these arguments (host-side, no launch): 0 = staged pipeline (layer products exact fp32 MFMA),
+   1 = one-launch forward with exact fp32 MFMA, 2 = one-launch forward with split-bf16 x 6 products.  For logs and benchmark lines. */
+int gsat_attn_fwd_kind(const gsat_attn_args* args);
 size_t gsat_attn_bwd_workspace_bytes(const gsat_attn_args* args);
 int gsat_attn_fwd(const gsat_attn_args* args, void* stream);
 int gsat_attn_bwd(const gsat_attn_args* args, const gsat_attn_grads* grads, void* stream);
