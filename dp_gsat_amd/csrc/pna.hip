@@ -338,6 +338,10 @@ __global__ __launch_bounds__(PNA_BLOCK) void k_pna_fwd(
         Acc4 aj, ae;
         aj.init(); ae.init();
         const float4 xi = on ? ld4(x + (size_t)row * H + c) : f4zero();
+        // node attention (att != NULL, eid == NULL): att holds one value per NODE and the edge weight is att[row] * att[source], the
+        // lifted attention of example/gsat.py:112-117 formed at the load (same product, same bits, no [E] tensor, no edge ids)
+        const bool natt = !HAS_EE && !LONG && att != nullptr && eid == nullptr;
+        const float na_row = natt ? att[row] : 1.f;
         if (LONG) {                 // hub row: fold the records k_pna_chunk_stats wrote for its chunks, in chunk order
             constexpr int GP = HAS_EE ? 2 : 1;
             const size_t rec = pna_rec_floats(H, GP);
@@ -360,11 +364,11 @@ __global__ __launch_bounds__(PNA_BLOCK) void k_pna_fwd(
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
                 j[u] = u < nb ? col[k + u] : 0;
-                e[u] = (u < nb && (att != nullptr || HAS_EE)) ? eid[k + u] : 0;
+                e[u] = (u < nb && !natt && (att != nullptr || HAS_EE)) ? eid[k + u] : 0;
             }
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
-                w[u] = (u < nb && att) ? att[e[u]] : 1.f;
+                w[u] = (u < nb && att) ? att[natt ? j[u] : e[u]] * na_row : 1.f;
                 xv[u] = (u < nb && on) ? ld4(x + (size_t)j[u] * H + c) : f4zero();
                 if (HAS_EE) ev[u] = (u < nb && on) ? ld4(edge_emb + (size_t)e[u] * H + c) : f4zero();
             }
@@ -713,12 +717,16 @@ __global__ void k_pna_tiles(const int32_t* __restrict__ node_ptr, const int32_t*
     desc[t] = make_int4(start, rowptr[start], rowptr_src[start], 0);
 }
 
-template <int LPR, int NAGG>
+// NATT: `att` is the NODE attention [N] and the edge weight att[row] * att[source] (no eid, no [E] attention tensor); `datt` is then
+// d node_att [N]: the destination's share of an edge (d w * att[source]) is summed in the row's own loop, the source's share
+// (d w * att[row]) is kept per slot in LDS (in the space of the unused edge ids) and summed in the per-source pass next to the rows;
+// spilled edges leave theirs in dw[slot] for k_pna_bwd_spill.
+template <int LPR, int NAGG, bool NATT>
 __global__ __launch_bounds__(TILE_BLOCK, 4) void k_pna_bwd_tile(
     const float* __restrict__ x, const float* __restrict__ att, const float* __restrict__ dout, const int32_t* __restrict__ rowptr,
     const int32_t* __restrict__ col, const int32_t* __restrict__ eid, const int4* __restrict__ desc,
     const int32_t* __restrict__ rowptr_src, const int32_t* __restrict__ slot_map, int H, int TE, int RCAP, float* dx,
-    float* __restrict__ dmsg, float* __restrict__ datt) {
+    float* __restrict__ dmsg, float* datt, float* __restrict__ dw) {
     constexpr int GPB = LaneGroups<LPR, TILE_BLOCK>::GPB;     // lane groups (rows in flight) per workgroup
     constexpr int RPW = 64 / LPR;                // rows covered by one wave-instruction
     constexpr int NSEG = NAGG * 2;
@@ -726,10 +734,13 @@ __global__ __launch_bounds__(TILE_BLOCK, 4) void k_pna_bwd_tile(
     float4* erow = smem4;                                        // [TE][LPR] gathered x_j row, then the edge's gradient row
     int* s_col = reinterpret_cast<int*>(erow + (size_t)TE * LPR);
     int* s_eid = s_col + TE;
+    float* s_w = reinterpret_cast<float*>(s_eid);                // NATT: [TE] the edge weight att[row] * att[source]; once its row is done, the source's share of d node_att
     float* s_att = reinterpret_cast<float*>(s_eid + TE);
     int* s_slot = reinterpret_cast<int*>(s_att + TE);            // [TE] by-source slots of the window's sources -> window-local by-destination slot
     int* s_rp = s_slot + TE;                                     // [RCAP+1] by-destination row pointers relative to the window's first slot
     int* s_rps = s_rp + RCAP + 1;                                // [RCAP+1] by-source row pointers relative to the window's first slot
+    float* s_na = reinterpret_cast<float*>(s_rps + RCAP + 1);    // [RCAP+1] NATT: node attention of the window's rows
+    float* s_dna = s_na + RCAP + 1;                              // [RCAP+1] NATT: the rows' share (as destinations) of d node_att
     const int tid = threadIdx.x, wave = tid >> 6;
     const LaneGroups<LPR, TILE_BLOCK> lg;
     const int grp = lg.grp < 0 ? GPB : lg.grp;          // idle lanes (LPR = 20: lanes 60-63) behave like a group beyond every row
@@ -758,10 +769,11 @@ __global__ __launch_bounds__(TILE_BLOCK, 4) void k_pna_bwd_tile(
     for (int i = tid; i <= nr; i += TILE_BLOCK) {
         s_rp[i] = rowptr[n0 + i] - k0;
         s_rps[i] = rowptr_src[n0 + i] - s0;
+        if (NATT) { s_na[i] = att[min(n0 + i, n1 - 1)]; s_dna[i] = 0.f; }
     }
     for (int i = tid; i < ne; i += TILE_BLOCK) {
         s_col[i] = col[k0 + i];
-        s_eid[i] = eid[k0 + i];
+        if (!NATT) s_eid[i] = eid[k0 + i];
     }
     for (int i = tid; i < nsl; i += TILE_BLOCK) s_slot[i] = slot_map[s0 + i] - k0;
     __syncthreads();
@@ -772,7 +784,17 @@ __global__ __launch_bounds__(TILE_BLOCK, 4) void k_pna_bwd_tile(
             __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(x + (size_t)s_col[i] * H + c),
                                              (__attribute__((address_space(3))) void*)(erow + (size_t)(base + wave * RPW) * LPR), 16, 0, 0);
     }
-    for (int i = tid; i < ne; i += TILE_BLOCK) s_att[i] = att ? att[s_eid[i]] : 1.f;
+    for (int i = tid; i < ne; i += TILE_BLOCK) {
+        if (NATT) {              // att[source] for the gradient, the edge weight for everything else: the slot's row by bisection of the row pointers
+            int lo = 0, hi = nr;
+            while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (s_rp[mid] <= i) lo = mid; else hi = mid; }
+            const float a = att[s_col[i]];
+            s_att[i] = a;
+            s_w[i] = a * s_na[lo];
+        } else {
+            s_att[i] = att ? att[s_eid[i]] : 1.f;
+        }
+    }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     // ---- destination rows ----------------------------------------------------------------------------------
@@ -791,10 +813,10 @@ __global__ __launch_bounds__(TILE_BLOCK, 4) void k_pna_bwd_tile(
             float w;
             float4 xv;
             if (k < ne) {
-                w = s_att[k];
+                w = NATT ? s_w[k] : s_att[k];
                 xv = on ? erow[(size_t)k * LPR + lane] : f4zero();
             } else {                                             // beyond the LDS edge capacity (hub rows): straight from memory
-                w = att ? att[eid[k0 + k]] : 1.f;
+                w = NATT ? att[col[k0 + k]] * s_na[row - n0] : (att ? att[eid[k0 + k]] : 1.f);
                 xv = on ? ld4(x + (size_t)col[k0 + k] * H + c) : f4zero();
             }
             if (k == beg) wfirst = w;
@@ -861,13 +883,15 @@ __global__ __launch_bounds__(TILE_BLOCK, 4) void k_pna_bwd_tile(
         for (int k = beg; k < end; ++k) {
             float w;
             float4 xj;
-            int e, j;
+            int e = 0, j;
             if (k < ne) {
-                w = s_att[k]; e = s_eid[k]; j = s_col[k];
+                w = NATT ? s_w[k] : s_att[k]; j = s_col[k];
+                if (!NATT) e = s_eid[k];
                 xj = on ? erow[(size_t)k * LPR + lane] : f4zero();
             } else {
-                e = eid[k0 + k]; j = col[k0 + k];
-                w = att ? att[e] : 1.f;
+                j = col[k0 + k];
+                if (!NATT) e = eid[k0 + k];
+                w = NATT ? att[j] * s_na[row - n0] : (att ? att[e] : 1.f);
                 xj = on ? ld4(x + (size_t)j * H + c) : f4zero();
             }
             const bool in_lds = k < ne && j >= n0 && j < n1;
@@ -884,7 +908,13 @@ __global__ __launch_bounds__(TILE_BLOCK, 4) void k_pna_bwd_tile(
             }
             if (datt) {
                 da = group_sum<LPR>(da);
-                if (lane == 0) datt[e] = da;
+                if (NATT) {
+                    if (lane == 0) {
+                        s_dna[row - n0] = fmaf(da, k < ne ? s_att[k] : att[j], s_dna[row - n0]);      // destination share: d w * att[source]
+                        const float share = da * s_na[row - n0];                                      // source share: d w * att[row]
+                        if (in_lds) s_w[k] = share; else dw[k0 + k] = share;                          // (the slot's weight is not read again)
+                    }
+                } else if (lane == 0) datt[e] = da;
             }
         }
     }
@@ -894,14 +924,17 @@ __global__ __launch_bounds__(TILE_BLOCK, 4) void k_pna_bwd_tile(
         if (!on) continue;
         const int sb = s_rps[j - n0], se = s_rps[j - n0 + 1];
         float4 acc = ld4(dx + (size_t)j * H + c);
+        float sw = 0.f;
         for (int s_ = sb; s_ < se; ++s_) {
             const int kl = s_ < nsl ? s_slot[s_] : slot_map[s0 + s_] - k0;
             if (kl >= 0 && kl < ne) {
                 const float4 v = erow[(size_t)kl * LPR + lane];
                 acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
+                if (NATT) sw += s_w[kl];
             }
         }
         st4(dx + (size_t)j * H + c, acc);
+        if (NATT && datt && lane == 0) datt[j] = s_dna[j - n0] + sw;      // destination share (this lane's own LDS store of the row loop) + source share
     }
 }
 
@@ -935,7 +968,8 @@ template <int LPR>
 __global__ __launch_bounds__(256) void k_pna_bwd_spill(const float* __restrict__ dmsg, const int4* __restrict__ desc, int TN, int TE,
                                                        const int32_t* __restrict__ rowptr_src, const int32_t* __restrict__ slot_map,
                                                        const int32_t* __restrict__ spill_rows, const int32_t* __restrict__ spill_count,
-                                                       int num_rows, int H, float* __restrict__ dx) {
+                                                       int num_rows, int H, float* __restrict__ dx, const float* __restrict__ dw,
+                                                       float* __restrict__ dna) {
     const LaneGroups<LPR, 256> lg;
     constexpr int GPB = LaneGroups<LPR, 256>::GPB;
     const int lane = lg.lane, c = lane * 4;
@@ -949,13 +983,16 @@ __global__ __launch_bounds__(256) void k_pna_bwd_spill(const float* __restrict__
         const int k0 = desc[t].y, ne = min(desc[t + 1].y - k0, TE);
         if (c >= H) continue;
         float4 acc = ld4(dx + (size_t)j * H + c);
+        float sw = 0.f;
         for (int s_ = sb; s_ < se; ++s_) {
             const int k = slot_map[s_];
             if (k >= k0 && k < k0 + ne) continue;
             const float4 v = ld4(dmsg + (size_t)k * H + c);
             acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
+            if (dna) sw += dw[k];
         }
         st4(dx + (size_t)j * H + c, acc);
+        if (dna && lane == 0) dna[j] += sw;                       // node attention: the source's share of its spilled edges
     }
 }
 
@@ -1001,17 +1038,17 @@ static int make_cfg(const int32_t* aggr, int A, const int32_t* scal, int S, floa
     return GSAT_OK;
 }
 
-template <int L, int NA>
+template <int L, int NA, bool NATT>
 static hipError_t pna_tile_allow_lds(size_t lds) {       // raise the kernel's dynamic-LDS limit once per size (not a stream operation)
     static size_t allowed = 0;
     if (lds <= allowed) return hipSuccess;
-    hipError_t e = hipFuncSetAttribute((const void*)k_pna_bwd_tile<L, NA>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipError_t e = hipFuncSetAttribute((const void*)k_pna_bwd_tile<L, NA, NATT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e == hipSuccess) allowed = lds;
     return e;
 }
 
 static size_t pna_tile_lds_bytes(int lpr, int edges_cap, int rows_cap) {
-    return (size_t)edges_cap * ((size_t)lpr * 16 + 16) + (size_t)(rows_cap + 1) * 8;
+    return (size_t)edges_cap * ((size_t)lpr * 16 + 16) + (size_t)(rows_cap + 1) * 16;      // rows + 4 per-slot words, 2 row pointers + node attention and its gradient per row
 }
 
 }  // namespace gsat
@@ -1071,6 +1108,14 @@ int gsat_pna_fwd(const float* x, const float* att, const float* edge_emb, const 
                  float avg_deg_lin, float avg_deg_log, float* out, void* stream_) {
     return pna_fwd_impl("gsat_pna_fwd", x, att, edge_emb, rowptr, col, eid, N, 0, H, aggregators, A, scalers, S, avg_deg_lin, avg_deg_log, out,
                         nullptr, nullptr, (hipStream_t)stream_);
+}
+
+int gsat_pna_fwd_node_att(const float* x, const float* node_att, const int32_t* rowptr, const int32_t* col, int64_t N, int64_t H,
+                          const int32_t* aggregators, int A, const int32_t* scalers, int S, float avg_deg_lin, float avg_deg_log, float* out,
+                          void* stream_) {
+    GSAT_REQUIRE(node_att, GSAT_ERR_ARG, "gsat_pna_fwd_node_att: null node attention");
+    return pna_fwd_impl("gsat_pna_fwd_node_att", x, node_att, nullptr, rowptr, col, /*eid=*/nullptr, N, 0, H, aggregators, A, scalers, S,
+                        avg_deg_lin, avg_deg_log, out, nullptr, nullptr, (hipStream_t)stream_);
 }
 
 size_t gsat_pna_long_row_floats(int64_t num_edges, int64_t H, int has_edge_emb) {
@@ -1155,7 +1200,7 @@ int gsat_pna_tile_plan(int64_t H, int64_t lds_budget_bytes, int32_t* rows_nomina
     GSAT_REQUIRE(rows_nominal && rows_slack && edges_cap, GSAT_ERR_ARG, "gsat_pna_tile_plan: null pointer");
     if (lds_budget_bytes <= 0) lds_budget_bytes = 80 * 1024;      // one workgroup per CU: measured best at C3 (profiles/r02_pna_bwd_probe.txt)
     GSAT_REQUIRE(lds_budget_bytes <= 160 * 1024, GSAT_ERR_ARG, "gsat_pna_tile_plan: LDS budget above 160 KiB");
-    int64_t te = (lds_budget_bytes - 1024) / ((int64_t)lpr * 16 + 16);
+    int64_t te = (lds_budget_bytes - 64) / ((int64_t)lpr * 16 + 16 + 8);     // + 16 bytes per window row, rows <= te / 2 (pna_tile_lds_bytes)
     te = te / 8 * 8;
     GSAT_REQUIRE(te >= 16, GSAT_ERR_UNSUPPORTED, "gsat_pna_tile_plan: LDS budget too small for H=%lld", (long long)H);
     int64_t half = std::max<int64_t>(4, te / 4 / 4 * 4);        // window = [nominal, nominal + slack] rows, ~2 in-edges per row
@@ -1186,45 +1231,68 @@ int gsat_pna_build_tiles(const int32_t* node_ptr, const int32_t* node_seg, const
     return GSAT_OK;
 }
 
-int gsat_pna_bwd_tiled(const float* x, const float* att, const float* dout, const int32_t* rowptr, const int32_t* col,
-                       const int32_t* eid, const int32_t* tile_desc, int64_t num_tiles, int rows_nominal, int rows_cap, int edges_cap,
-                       const int32_t* rowptr_src, const int32_t* slot_dst_of_srcslot, int64_t N, int64_t E, int64_t H,
-                       const int32_t* aggregators, int A, const int32_t* scalers, int S, const int32_t* spill_rows,
-                       const int32_t* spill_count, float* dx, float* dmsg, float* datt, void* stream_) {
-    hipStream_t stream = (hipStream_t)stream_;
-    GSAT_REQUIRE(N >= 0 && N < (1ll << 31) && E >= 0 && num_tiles >= 0, GSAT_ERR_ARG, "gsat_pna_bwd_tiled: bad extents");
+static int pna_bwd_tiled_impl(const char* who, bool natt, const float* x, const float* att, const float* dout, const int32_t* rowptr,
+                              const int32_t* col, const int32_t* eid, const int32_t* tile_desc, int64_t num_tiles, int rows_nominal,
+                              int rows_cap, int edges_cap, const int32_t* rowptr_src, const int32_t* slot_dst_of_srcslot, int64_t N,
+                              int64_t E, int64_t H, const int32_t* aggregators, int A, const int32_t* scalers, int S,
+                              const int32_t* spill_rows, const int32_t* spill_count, float* dx, float* dmsg, float* datt, float* dw,
+                              hipStream_t stream) {
+    GSAT_REQUIRE(N >= 0 && N < (1ll << 31) && E >= 0 && num_tiles >= 0, GSAT_ERR_ARG, "%s: bad extents", who);
     PnaCfg cfg;
     int rc = make_cfg(aggregators, A, scalers, S, 1.f, 1.f, &cfg);
     if (rc) return rc;
     const int nagg = fixed_aggregators(cfg);
-    GSAT_REQUIRE(nagg, GSAT_ERR_UNSUPPORTED, "gsat_pna_bwd_tiled: only (mean,min,max,std[,sum]) with the identity scaler");
+    GSAT_REQUIRE(nagg, GSAT_ERR_UNSUPPORTED, "%s: only (mean,min,max,std[,sum]) with the identity scaler", who);
     if (N == 0) return GSAT_OK;
     const int lpr = pna_lpr(H);
-    GSAT_REQUIRE(lpr, GSAT_ERR_UNSUPPORTED, "gsat_pna_bwd_tiled: H=%lld must be a multiple of 4 and <= 256", (long long)H);
-    GSAT_REQUIRE(x && dout && rowptr && tile_desc && rowptr_src && dx && rows_nominal > 0 && rows_cap >= rows_nominal && rows_cap <= 2 * rows_nominal && edges_cap > 0, GSAT_ERR_ARG, "gsat_pna_bwd_tiled: null pointer");
-    GSAT_REQUIRE(E == 0 || (col && eid && slot_dst_of_srcslot && dmsg), GSAT_ERR_ARG, "gsat_pna_bwd_tiled: null edge arrays");
+    GSAT_REQUIRE(lpr, GSAT_ERR_UNSUPPORTED, "%s: H=%lld must be a multiple of 4 and <= 256", who, (long long)H);
+    GSAT_REQUIRE(x && dout && rowptr && tile_desc && rowptr_src && dx && rows_nominal > 0 && rows_cap >= rows_nominal && rows_cap <= 2 * rows_nominal && edges_cap > 0, GSAT_ERR_ARG, "%s: null pointer", who);
+    GSAT_REQUIRE(E == 0 || (col && (natt || eid) && slot_dst_of_srcslot && dmsg), GSAT_ERR_ARG, "%s: null edge arrays", who);
+    GSAT_REQUIRE(!natt || (att && (!datt || dw || E == 0)), GSAT_ERR_ARG, "%s: node attention needs node_att and, for its gradient, the [E] scratch dw", who);
     const size_t lds = pna_tile_lds_bytes(lpr, edges_cap, rows_cap);
-    GSAT_REQUIRE(lds <= 160 * 1024, GSAT_ERR_ARG, "gsat_pna_bwd_tiled: tile needs %zu bytes of LDS", lds);
-#define GO(L, NA)                                                                                                            \
+    GSAT_REQUIRE(lds <= 160 * 1024, GSAT_ERR_ARG, "%s: tile needs %zu bytes of LDS", who, lds);
+#define GO(L, NA, NT)                                                                                                        \
     do {                                                                                                                     \
-        GSAT_CHECK_HIP((pna_tile_allow_lds<L, NA>(lds)));                                                                    \
-        k_pna_bwd_tile<L, NA><<<(int)num_tiles, TILE_BLOCK, lds, stream>>>(x, att, dout, rowptr, col, eid, (const int4*)tile_desc,     \
-                                                                          rowptr_src, slot_dst_of_srcslot, (int)H, edges_cap, rows_cap, dx, dmsg, datt); \
+        GSAT_CHECK_HIP((pna_tile_allow_lds<L, NA, NT>(lds)));                                                                \
+        k_pna_bwd_tile<L, NA, NT><<<(int)num_tiles, TILE_BLOCK, lds, stream>>>(x, att, dout, rowptr, col, eid, (const int4*)tile_desc,     \
+                                                                          rowptr_src, slot_dst_of_srcslot, (int)H, edges_cap, rows_cap, dx, dmsg, datt, dw); \
     } while (0)
-#define CALL(L) do { if (nagg == 4) GO(L, 4); else GO(L, 5); } while (0)
+#define CALL(L) do { if (natt) { if (nagg == 4) GO(L, 4, true); else GO(L, 5, true); } else { if (nagg == 4) GO(L, 4, false); else GO(L, 5, false); } } while (0)
     if (num_tiles > 0) { GSAT_LPR_DISPATCH(lpr, CALL); }
 #undef CALL
 #undef GO
     GSAT_LAUNCH_CHECK();
     if (E > 0) {
-        GSAT_REQUIRE(spill_rows && spill_count, GSAT_ERR_ARG, "gsat_pna_bwd_tiled: null spill list (gsat_pna_build_tiles)");
+        GSAT_REQUIRE(spill_rows && spill_count, GSAT_ERR_ARG, "%s: null spill list (gsat_pna_build_tiles)", who);
         const int nb = (int)std::min<int64_t>(std::max<int64_t>(ceil_div(N, 8 * 4 * (64 / lpr)), 1), 256 * 8);     // sized for ~1/8 of the sources
-#define CALL(L) k_pna_bwd_spill<L><<<nb, 256, 0, stream>>>(dmsg, (const int4*)tile_desc, rows_nominal, edges_cap, rowptr_src, slot_dst_of_srcslot, spill_rows, spill_count, (int)N, (int)H, dx)
+        const float* dw_in = (natt && datt) ? dw : nullptr;
+        float* dna = (natt && datt) ? datt : nullptr;
+#define CALL(L) k_pna_bwd_spill<L><<<nb, 256, 0, stream>>>(dmsg, (const int4*)tile_desc, rows_nominal, edges_cap, rowptr_src, slot_dst_of_srcslot, spill_rows, spill_count, (int)N, (int)H, dx, dw_in, dna)
         GSAT_LPR_DISPATCH(lpr, CALL);
 #undef CALL
         GSAT_LAUNCH_CHECK();
     }
     return GSAT_OK;
+}
+
+int gsat_pna_bwd_tiled(const float* x, const float* att, const float* dout, const int32_t* rowptr, const int32_t* col,
+                       const int32_t* eid, const int32_t* tile_desc, int64_t num_tiles, int rows_nominal, int rows_cap, int edges_cap,
+                       const int32_t* rowptr_src, const int32_t* slot_dst_of_srcslot, int64_t N, int64_t E, int64_t H,
+                       const int32_t* aggregators, int A, const int32_t* scalers, int S, const int32_t* spill_rows,
+                       const int32_t* spill_count, float* dx, float* dmsg, float* datt, void* stream_) {
+    return pna_bwd_tiled_impl("gsat_pna_bwd_tiled", false, x, att, dout, rowptr, col, eid, tile_desc, num_tiles, rows_nominal, rows_cap, edges_cap,
+                              rowptr_src, slot_dst_of_srcslot, N, E, H, aggregators, A, scalers, S, spill_rows, spill_count, dx, dmsg, datt,
+                              nullptr, (hipStream_t)stream_);
+}
+
+int gsat_pna_bwd_tiled_node_att(const float* x, const float* node_att, const float* dout, const int32_t* rowptr, const int32_t* col,
+                                const int32_t* tile_desc, int64_t num_tiles, int rows_nominal, int rows_cap, int edges_cap,
+                                const int32_t* rowptr_src, const int32_t* slot_dst_of_srcslot, int64_t N, int64_t E, int64_t H,
+                                const int32_t* aggregators, int A, const int32_t* scalers, int S, const int32_t* spill_rows,
+                                const int32_t* spill_count, float* dx, float* dmsg, float* dnode_att, float* dw, void* stream_) {
+    return pna_bwd_tiled_impl("gsat_pna_bwd_tiled_node_att", true, x, node_att, dout, rowptr, col, nullptr, tile_desc, num_tiles, rows_nominal,
+                              rows_cap, edges_cap, rowptr_src, slot_dst_of_srcslot, N, E, H, aggregators, A, scalers, S, spill_rows, spill_count,
+                              dx, dmsg, dnode_att, dw, (hipStream_t)stream_);
 }
 
 }  // extern "C"

@@ -13,7 +13,7 @@ import torch.nn as nn
 
 from .get_model import MLP
 from .graph_index import get_index, sync_free
-from .ops import ExtractorAttention, InfoLoss, Lift, Sample, Symmetrise, new_seed
+from .ops import ExtractorAttention, InfoLoss, Lift, LiftedAttention, Sample, Symmetrise, new_seed
 
 
 class ExtractorMLP(nn.Module):
@@ -108,8 +108,9 @@ def gumbel_sigmoid(logits, tau=1.0, eps=1e-10, noise=None):
 
 
 def lift_node_att_to_edge_att(node_att, edge_index):
-    """example/gsat.py:112-117."""
-    return Lift.apply(node_att, get_index(edge_index, node_att.shape[0]))
+    """example/gsat.py:112-117.  Returns a lazy view (ops.LiftedAttention): the PNA aggregation forms node_att[src] * node_att[dst] at
+    its mask load; any other use writes the [E, 1] tensor out on first touch."""
+    return LiftedAttention(node_att, get_index(edge_index, node_att.shape[0]))
 
 
 def symmetrise_edge_att(att, edge_index, num_nodes):

@@ -26,9 +26,60 @@ def _flat_att(att: Optional[torch.Tensor], E: int) -> Optional[torch.Tensor]:
     """edge_atten is [E,1] in the reference (src/models/conv_layers.py:31-32); kernels take [E]."""
     if att is None:
         return None
+    if isinstance(att, LiftedAttention):
+        raise TypeError("LiftedAttention must be written out (att.edge()) before it enters an autograd Function")
     if att.numel() != E:
         raise ValueError(f"edge_atten has {att.numel()} entries, expected {E}")
     return _f32c(att).view(-1)
+
+
+class LiftedAttention:
+    """``node_att[src] * node_att[dst]`` (example/gsat.py:112-117) that has not been written out: the PNA aggregation forms the product
+    at its mask load (gsat_pna_*_node_att), so a node-attention step needs no [E] tensor and no lift kernels.  Every other consumer --
+    a torch function, an operator, an attribute -- gets the [E, 1] tensor of ``Lift`` (built once, on first use, inside autograd)."""
+
+    def __init__(self, node_att: torch.Tensor, index: BatchIndex):
+        if node_att.numel() != index.N:
+            raise ValueError("node attention must have one entry per node")
+        self.node_att, self.index, self._edge = node_att, index, None
+
+    def edge(self) -> torch.Tensor:
+        if self._edge is None:
+            self._edge = Lift.apply(self.node_att, self.index)
+        return self._edge
+
+    @property
+    def shape(self):
+        return torch.Size((self.index.E, 1))
+
+    def numel(self):
+        return self.index.E
+
+    @classmethod
+    def __torch_function__(cls, func, types, args=(), kwargs=None):
+        from torch.utils._pytree import tree_map
+        unwrap = lambda a: a.edge() if isinstance(a, LiftedAttention) else a
+        return func(*tree_map(unwrap, args), **tree_map(unwrap, kwargs or {}))
+
+    def __getattr__(self, name):            # anything a tensor has and this view does not
+        if name.startswith("__") and name.endswith("__"):
+            raise AttributeError(name)
+        return getattr(self.edge(), name)
+
+    def __repr__(self):
+        return f"LiftedAttention(nodes={self.index.N}, edges={self.index.E}, materialised={self._edge is not None})"
+
+
+def _forward_operator(name):
+    def op(self, *args):
+        return getattr(self.edge(), name)(*args)
+    op.__name__ = name
+    return op
+
+
+for _name in ("__mul__", "__rmul__", "__add__", "__radd__", "__sub__", "__rsub__", "__truediv__", "__rtruediv__", "__neg__", "__pow__",
+              "__getitem__", "__len__", "__iter__", "__lt__", "__le__", "__gt__", "__ge__", "__matmul__", "__float__"):
+    setattr(LiftedAttention, _name, _forward_operator(_name))
 
 
 class MaskedSumAggregate(torch.autograd.Function):
@@ -74,6 +125,8 @@ class MaskedSumAggregate(torch.autograd.Function):
 
 
 def masked_sum_aggregate(x, index, att=None, edge_emb=None, eps: float = 0.0):
+    if isinstance(att, LiftedAttention):
+        att = att.edge()                 # written out here, under autograd (inside Function.forward it would be cut from the graph)
     return MaskedSumAggregate.apply(x, att, edge_emb, index, 1.0 + eps)
 
 
@@ -117,9 +170,12 @@ class PnaAggregate(torch.autograd.Function):
     replaces: PNAConvSimple.message/aggregate (src/models/conv_layers.py:166-185, 193-259)."""
 
     @staticmethod
-    def forward(ctx, x, att, edge_emb, index: BatchIndex, aggr_codes, scaler_codes, avg_lin: float, avg_log: float):
+    def forward(ctx, x, att, edge_emb, index: BatchIndex, aggr_codes, scaler_codes, avg_lin: float, avg_log: float, node_att=None):
         import ctypes
         x = _f32c(x)
+        if node_att is not None:
+            return PnaAggregate._forward_node_att(ctx, x, node_att, index, aggr_codes, scaler_codes, avg_lin, avg_log)
+        ctx.node_att = False
         attf = _flat_att(att, index.E)
         edge_emb = _f32c(edge_emb)
         N, H = x.shape
@@ -147,8 +203,54 @@ class PnaAggregate(torch.autograd.Function):
         return out
 
     @staticmethod
+    def _forward_node_att(ctx, x, node_att, index, aggr_codes, scaler_codes, avg_lin, avg_log):
+        """Edge weight = node_att[row] * node_att[source] formed inside the kernels (pna_aggregate checked that the tiled backward covers
+        this batch)."""
+        import ctypes
+        N, H = x.shape
+        if N != index.N or node_att.numel() != N:
+            raise ValueError(f"x / node attention have {N} / {node_att.numel()} rows but the index was built for {index.N} nodes")
+        na = _f32c(node_att).view(-1)
+        A, S = len(aggr_codes), len(scaler_codes)
+        a_arr = (ctypes.c_int32 * A)(*aggr_codes)
+        s_arr = (ctypes.c_int32 * S)(*scaler_codes)
+        out = torch.empty(N, S * A * 2 * H, dtype=torch.float32, device=x.device)
+        call("gsat_pna_fwd_node_att", ptr(x), ptr(na), ptr(index.rowptr_dst), ptr(index.src_by_dst), N, H, a_arr, A, s_arr, S,
+             float(avg_lin), float(avg_log), ptr(out), stream())
+        ctx.save_for_backward(x, na)
+        ctx.index, ctx.node_att = index, True
+        ctx.cfg = (tuple(aggr_codes), tuple(scaler_codes), float(avg_lin), float(avg_log))
+        ctx.att_shape = node_att.shape
+        return out
+
+    @staticmethod
+    def _backward_node_att(ctx, dout):
+        import ctypes
+        x, na = ctx.saved_tensors
+        index = ctx.index
+        aggr_codes, scaler_codes, _, _ = ctx.cfg
+        dout = _f32c(dout)
+        N, H = x.shape
+        A, S = len(aggr_codes), len(scaler_codes)
+        a_arr = (ctypes.c_int32 * A)(*aggr_codes)
+        s_arr = (ctypes.c_int32 * S)(*scaler_codes)
+        dev = x.device
+        need_att = ctx.needs_input_grad[8]
+        tile_ptr, T, rows_nominal, rows_cap, edges_cap, spill = index.pna_tiles(H)
+        dmsg = torch.empty(max(index.E, 1), H, dtype=torch.float32, device=dev)[: index.E]
+        dw = torch.empty(max(index.E, 1), dtype=torch.float32, device=dev) if need_att else None
+        dna = torch.empty(N, dtype=torch.float32, device=dev) if need_att else None
+        dx = torch.empty_like(x)
+        call("gsat_pna_bwd_tiled_node_att", ptr(x), ptr(na), ptr(dout), ptr(index.rowptr_dst), ptr(index.src_by_dst), ptr(tile_ptr), T,
+             rows_nominal, rows_cap, edges_cap, ptr(index.rowptr_src), ptr(index.slot_dst_of_srcslot), N, index.E, H, a_arr, A, s_arr, S,
+             ptr(spill[1:]), ptr(spill[:1]), ptr(dx), ptr(dmsg), ptr(dna), ptr(dw), stream())
+        return dx, None, None, None, None, None, None, None, (dna.view(ctx.att_shape) if need_att else None)
+
+    @staticmethod
     def backward(ctx, dout):
         import ctypes
+        if ctx.node_att:
+            return PnaAggregate._backward_node_att(ctx, dout)
         x, attf, edge_emb = ctx.saved_tensors
         index = ctx.index
         aggr_codes, scaler_codes, avg_lin, avg_log = ctx.cfg
@@ -177,7 +279,7 @@ class PnaAggregate(torch.autograd.Function):
             call("gsat_pna_bwd_tiled", ptr(x), ptr(attf), ptr(dout), ptr(index.rowptr_dst), ptr(index.src_by_dst), ptr(index.eid_by_dst),
                  ptr(tile_ptr), T, rows_nominal, rows_cap, edges_cap, ptr(index.rowptr_src), ptr(index.slot_dst_of_srcslot), N, index.E, H,
                  a_arr, A, s_arr, S, ptr(spill[1:]), ptr(spill[:1]), ptr(dx), ptr(dmsg), ptr(datt), stream())
-            return dx, (datt.view(ctx.att_shape) if need_att else None), None, None, None, None, None, None
+            return dx, (datt.view(ctx.att_shape) if need_att else None), None, None, None, None, None, None, None
         dx_self = torch.empty_like(x)
         dee = torch.empty_like(edge_emb) if need_ee else None
         if hubs is not None:
@@ -193,12 +295,20 @@ class PnaAggregate(torch.autograd.Function):
         call("gsat_aggr_sum_fwd", ptr(dmsg), ptr(dx_self), None, None, ptr(index.rowptr_src),
              ptr(index.slot_dst_of_srcslot), None, N, index.E, H, 1.0, ptr(dx),
              ptr(index.long_rows[1]), ptr(index.partial(H)) if index.long_rows[1] is not None else None, stream())
-        return dx, (datt.view(ctx.att_shape) if need_att else None), dee, None, None, None, None, None
+        return dx, (datt.view(ctx.att_shape) if need_att else None), dee, None, None, None, None, None, None
 
 
 def pna_aggregate(x, index, att, edge_emb, aggregators, scalers, avg_deg):
     a = [AGGREGATOR_CODES[k] for k in aggregators]
     s = [SCALER_CODES[k] for k in scalers]
+    if isinstance(att, LiftedAttention):
+        # lifted node attention: formed inside the aggregation kernels when the batch takes the one-launch (tiled) backward -- no edge
+        # features, the reference's aggregator set, no hub rows, rows of >= 64 channels; anything else gets the [E, 1] tensor
+        if (edge_emb is None and att.index is index and _FIXED_PNA.get((tuple(a), tuple(s))) and index.long_rows_nowait[0] is None
+                and os.environ.get("GSAT_PNA_TILED", "1") != "0" and os.environ.get("GSAT_NODE_ATT_LIFT", "0") != "1"
+                and att._edge is None and index.pna_tiles(x.shape[1])):
+            return PnaAggregate.apply(x, None, None, index, a, s, avg_deg["lin"], avg_deg["log"], att.node_att)
+        att = att.edge()
     return PnaAggregate.apply(x, att, edge_emb, index, a, s, avg_deg["lin"], avg_deg["log"])
 
 

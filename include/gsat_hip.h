@@ -253,6 +253,26 @@ int gsat_pna_bwd_tiled(const float* x, const float* att, const float* dout, cons
                        const int32_t* aggregators, int num_aggregators, const int32_t* scalers, int num_scalers,
                        const int32_t* spill_rows, const int32_t* spill_count, float* dx, float* dmsg, float* datt, void* stream);
 
+/*
+ * Node attention without the lift (example/gsat.py:112-117 `edge_att = node_att[src] * node_att[dst]`, then PNAConvSimple.message): the
+ * aggregation kernels form the edge weight node_att[row] * node_att[source] at the load -- the same product, bit for bit, as
+ * gsat_lift_fwd followed by gsat_pna_fwd -- so there is no [E] attention tensor, no edge-id indirection and no lift kernel either way.
+ *   gsat_pna_fwd_node_att:        as gsat_pna_fwd without edge_emb / hub chunks; node_att [N].
+ *   gsat_pna_bwd_tiled_node_att:  as gsat_pna_bwd_tiled; dnode_att [N] (may be NULL) = sum over the edges of a node, as destination and as
+ *                                 source, of d w_e * node_att[other end], summed in CSR order inside the two passes of the tile kernel
+ *                                 (bitwise reproducible); dw [E] is scratch for the spilled edges' shares (needed when dnode_att != NULL).
+ * replaces: GSAT.lift_node_att_to_edge_att + its autograd backward fused into PNAConvSimple's aggregation (src/models/pna.py:57-59).
+ */
+int gsat_pna_fwd_node_att(const float* x, const float* node_att, const int32_t* rowptr, const int32_t* col, int64_t num_rows, int64_t H,
+                          const int32_t* aggregators, int num_aggregators, const int32_t* scalers, int num_scalers, float avg_deg_lin,
+                          float avg_deg_log, float* out, void* stream);
+int gsat_pna_bwd_tiled_node_att(const float* x, const float* node_att, const float* dout, const int32_t* rowptr, const int32_t* col,
+                                const int32_t* tile_desc, int64_t num_tiles, int rows_nominal, int rows_cap, int edges_cap,
+                                const int32_t* rowptr_src, const int32_t* slot_dst_of_srcslot, int64_t num_rows, int64_t num_edges, int64_t H,
+                                const int32_t* aggregators, int num_aggregators, const int32_t* scalers, int num_scalers,
+                                const int32_t* spill_rows, const int32_t* spill_count, float* dx, float* dmsg, float* dnode_att, float* dw,
+                                void* stream);
+
 /* ================================ BatchNorm1d over node rows ================================= */
 
 /*

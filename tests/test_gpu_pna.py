@@ -183,6 +183,69 @@ def test_pna_tiled_backward(dev, monkeypatch, H, lds_budget, aligned):
     close(dx, dx0, 1e-5, what="dx tiled vs two-pass")
 
 
+@pytest.mark.parametrize("H", [64, 80, 128, 256])
+@pytest.mark.parametrize("lds_budget", [0, 6144])            # default windows / tiny windows: most edges spill, hub rows overflow the LDS edge capacity
+@pytest.mark.parametrize("aligned", [True, False])
+def test_pna_node_attention_without_lift(dev, monkeypatch, H, lds_budget, aligned):
+    """Node attention formed inside the aggregation kernels (gsat_pna_*_node_att, ops.LiftedAttention) vs the lifted [E, 1] tensor
+    through the same kernels (forward output and dx bit-identical: the edge weight is the same product) and vs the oracle
+    (example/gsat.py:112-117 + conv_layers.py:166-185); d node_att sums in CSR order instead of the lift kernel's, equal within fp32
+    rounding; spilled edges, a hub row, isolated nodes, rows without in-edges; bitwise reproducible."""
+    from dp_gsat_amd.graph_index import BatchIndex
+    from dp_gsat_amd.ops import LiftedAttention, PnaAggregate, pna_aggregate
+    monkeypatch.setenv("GSAT_PNA_TILE_LDS", str(lds_budget))
+    ei, batch, N = random_batch(17 + H, 24, 1, 40)
+    hub = torch.arange(1, 200)
+    star = torch.stack([torch.cat([hub, torch.zeros_like(hub)]), torch.cat([torch.zeros_like(hub), hub])]) + (N - 200 if N > 400 else 0)
+    ei = shuffle_edges(torch.cat([ei, star.clamp_(max=N - 1)], dim=1), 2)
+    g = torch.Generator().manual_seed(H + 1)
+    x = torch.randn(N, H, generator=g)
+    x[::5] = x[::5].relu()
+    na = torch.rand(N, 1, generator=g)
+    na[::7] = 0.0                                              # zero attention: every edge of the node carries weight 0
+    aggr = ["mean", "min", "max", "std", "sum"] if H == 80 else ["mean", "min", "max", "std"]
+    avg = {"lin": 1.0, "log": 1.0}
+    go = torch.randn(N, len(aggr) * 2 * H, generator=g)
+    ref = {}
+    for dt in (torch.float32, torch.float64):
+        xo, ao = x.to(dt).clone().requires_grad_(True), na.to(dt).clone().requires_grad_(True)
+        out = oops.pna_aggregate(xo, ei, oops.lift_node_att_to_edge_att(ao, ei), aggr, ["identity"], avg)
+        out.backward(go.to(dt))
+        ref[dt] = (out.detach(), xo.grad, ao.grad)
+
+    def run(lift_free):
+        ix = BatchIndex(ei.to(dev), N)
+        if aligned:
+            ix.graphs(batch.to(dev))
+        xd, ad = x.to(dev).requires_grad_(True), na.to(dev).requires_grad_(True)
+        calls.clear()
+        att = LiftedAttention(ad, ix)
+        if not lift_free:
+            att = att.edge()
+        out = pna_aggregate(xd, ix, att, None, aggr, ["identity"], avg)
+        out.backward(go.to(dev))
+        return out.detach(), xd.grad, ad.grad, list(calls)
+
+    from dp_gsat_amd import _lib
+    calls, real = [], _lib.call
+    monkeypatch.setattr("dp_gsat_amd.ops.call", lambda name, *a: (calls.append(name), real(name, *a))[1])
+    tiles = bool(BatchIndex(ei.to(dev), N).pna_tiles(H))
+    out, dx, dna, names = run(True)
+    if tiles:                  # (a budget too small for the width: pna_aggregate writes the tensor out and takes the two-pass path)
+        assert names == ["gsat_pna_fwd_node_att", "gsat_pna_bwd_tiled_node_att"], names            # no lift kernel, no [E] tensor
+    close(out, ref[torch.float32][0], ref64=ref[torch.float64][0], what="out")
+    close(dx, ref[torch.float32][1], ref64=ref[torch.float64][1], what="dx")
+    close(dna, ref[torch.float32][2], ref64=ref[torch.float64][2], what="d node_att")
+    out2, dx2, dna2, _ = run(True)
+    assert torch.equal(out, out2) and torch.equal(dx, dx2) and torch.equal(dna, dna2)          # bitwise reproducible
+    out0, dx0, dna0, names0 = run(False)
+    assert "gsat_lift_fwd" in names0 and "gsat_lift_bwd" in names0
+    assert torch.equal(out, out0)                                                                # same products, same order
+    if tiles:
+        assert torch.equal(dx, dx0)
+    close(dna, dna0, 1e-5, what="d node_att: in-kernel vs lift backward")
+
+
 def test_pna_tiled_backward_under_back_to_back_graph_replays(dev):
     """The whole per-batch pipeline (index build -> window build with its spill-source list -> PNA forward -> tiled backward)
     captured into one hipGraph and replayed back to back WITHOUT host syncs must reproduce the eager result bit for bit on every
