@@ -11,7 +11,7 @@ import torch
 import torch.nn as nn
 
 from .graph_index import get_index
-from .ops import MaskedSumAggregate, masked_sum_aggregate, pna_aggregate
+from .ops import MaskedSumAggregate, masked_sum_aggregate, pna_aggregate, pna_conv
 
 
 def _index_of(edge_index, x, index):
@@ -74,8 +74,13 @@ class PNAConvSimple(nn.Module):
         self.post_nn = nn.Sequential(*modules)
 
     def forward(self, x, edge_index, edge_attr=None, edge_atten=None, index=None):
-        agg = pna_aggregate(x, _index_of(edge_index, x, index), edge_atten, edge_attr, self.aggregators,
-                            self.scalers, self.avg_deg)
+        index = _index_of(edge_index, x, index)
+        if len(self.post_nn) == 1:           # one Linear behind the aggregation: one autograd node on the compact aggregate when possible
+            lin = self.post_nn[0]
+            out = pna_conv(x, index, edge_atten, edge_attr, self.aggregators, self.scalers, self.avg_deg, lin.weight, lin.bias)
+            if out is not None:
+                return out
+        agg = pna_aggregate(x, index, edge_atten, edge_attr, self.aggregators, self.scalers, self.avg_deg)
         if agg.shape[1] != self.post_nn[0].in_features:
             raise ValueError(f"PNAConvSimple was built for F_in={self.F_in} but the message is {agg.shape[1]} wide")
         return self.post_nn(agg)

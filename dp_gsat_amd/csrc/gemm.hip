@@ -14,6 +14,7 @@
 // Weight gradients reduce over the row dimension (K = #rows, huge; M x N small): blockIdx.z splits K and
 // writes partial slabs that a second kernel sums in slab order (deterministic, no atomics).
 #include "common.h"
+#include "pna_math.h"
 #include <cstdlib>
 
 namespace gsat {
@@ -230,6 +231,63 @@ __device__ __forceinline__ void load_split_kmajor(StageKM& s, const float* __res
         s.v[j] = (k < K && c0 + cp < Ccols) ? *reinterpret_cast<const float2*>(X + (size_t)k * ld + c0 + cp) : make_float2(0.f, 0.f);
     }
 }
+// the same two stagings for the PNA aggregate as a virtual operand (pna_math.h: PnaVirt): x_j columns from the compact aggregate, x_i
+// columns recomputed from x and the row's coefficient pair.  A 32-wide k slab / a COLS-wide column tile lies inside ONE segment (the
+// dispatch requires H % 32 == 0 resp. H % COLS == 0), so the choice is uniform over the workgroup.  Loads are issued unconditionally
+// (row clamped) into the stage registers like the plain loaders'; the arithmetic runs when the slab is stored to LDS, a whole MFMA slab
+// later, so nothing waits on a load.
+template <int ROWS>
+__device__ __forceinline__ void load_kcontig_virt(StageKC& s, const PnaVirt& v, int r0, int R, int k0, int t) {
+    const int seg = k0 / v.H, c = k0 - seg * v.H + (t & 7) * 4, a = seg >> 1;
+#pragma unroll
+    for (int p = 0; p < ROWS / 32; ++p) {
+        const int r = min(r0 + (t >> 3) + 32 * p, R - 1);
+        s.v[p] = (seg & 1) ? ld4(v.aggj + (size_t)r * (v.NAGG * v.H) + a * v.H + c) : ld4(v.x + (size_t)r * v.H + c);
+    }
+}
+// coef: LDS image of scal rows [r0, r0 + ROWS) (8 floats each), staged once per workgroup
+template <int ROWS>
+__device__ __forceinline__ void synth_kcontig_virt(StageKC& s, const float* coef, const PnaVirt& v, int r0, int R, int k0, int t) {
+    const int seg = k0 / v.H, a = seg >> 1, co = pna_coef_offset(a);
+    if (seg & 1) return;                                         // x_j columns: as loaded (rows beyond R are never stored to C)
+#pragma unroll
+    for (int p = 0; p < ROWS / 32; ++p) {
+        const float2 cf = *reinterpret_cast<const float2*>(coef + ((t >> 3) + 32 * p) * 8 + co);
+        const float4 x = s.v[p];
+        s.v[p] = make_float4(pna_self(a, x.x, cf), pna_self(a, x.y, cf), pna_self(a, x.z, cf), pna_self(a, x.w, cf));
+    }
+}
+template <int COLS>
+__device__ __forceinline__ void load_split_kmajor_virt(StageKM& s, const PnaVirt& v, int c0, int k0, int K, int t) {
+    constexpr int PAIRS = COLS / 2;
+    if (t >= PAIRS * 4) return;
+    const int cp = (t % PAIRS) * 2, k8 = t / PAIRS;
+    const int seg = c0 / v.H, c = c0 - seg * v.H + cp, a = seg >> 1;
+    const float* base = (seg & 1) ? v.aggj + a * v.H + c : v.x + c;
+    const size_t ld = (seg & 1) ? (size_t)v.NAGG * v.H : (size_t)v.H;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const int k = min(k0 + k8 * 8 + j, K - 1);
+        s.v[j] = *reinterpret_cast<const float2*>(base + (size_t)k * ld);
+    }
+}
+// coef: LDS image of scal rows [k0, k0 + 32) of the slab
+template <int COLS>
+__device__ __forceinline__ void synth_kmajor_virt(StageKM& s, const float* coef, const PnaVirt& v, int c0, int k0, int K, int t) {
+    constexpr int PAIRS = COLS / 2;
+    if (t >= PAIRS * 4) return;
+    const int k8 = t / PAIRS;
+    const int seg = c0 / v.H, a = seg >> 1, co = pna_coef_offset(a);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        float2 x = s.v[j];
+        if (!(seg & 1)) {
+            const float2 cf = *reinterpret_cast<const float2*>(coef + (k8 * 8 + j) * 8 + co);
+            x = make_float2(pna_self(a, x.x, cf), pna_self(a, x.y, cf));
+        }
+        s.v[j] = k0 + k8 * 8 + j < K ? x : make_float2(0.f, 0.f);          // rows beyond K must not enter the reduction
+    }
+}
 template <int COLS>
 __device__ __forceinline__ void store_split_kmajor(const StageKM& s, unsigned char* __restrict__ hi, unsigned char* __restrict__ lo, int t) {
     constexpr int PAIRS = COLS / 2;
@@ -249,10 +307,11 @@ __device__ __forceinline__ void store_split_kmajor(const StageKM& s, unsigned ch
     }
 }
 
-template <bool A_T, bool B_T, int TM, int TN>
-__global__ __launch_bounds__(GT) void k_gemm_bf16x3(const float* __restrict__ A, int64_t lda, const float* __restrict__ B, int64_t ldb,
+// VIRT = 1: A (k-contiguous, !A_T) is the virtual PNA aggregate `pv` (post_nn forward); VIRT = 2: B (k-major, !B_T) is (post_nn dW)
+template <bool A_T, bool B_T, int TM, int TN, int VIRT = 0>
+__global__ __launch_bounds__(GT, (VIRT == 1 && TM == 2 && TN == 2) ? 3 : 1) void k_gemm_bf16x3(const float* __restrict__ A, int64_t lda, const float* __restrict__ B, int64_t ldb,
                                                     float* __restrict__ C, int64_t ldc, int M, int N, int K, int k_per_split,
-                                                    const float* __restrict__ bias, int accumulate, size_t slab_stride) {
+                                                    const float* __restrict__ bias, int accumulate, size_t slab_stride, const PnaVirt pv = PnaVirt{}) {
     constexpr int GM = 64 * TM, GN = 64 * TN;
     constexpr int EP_LD = 36;
     constexpr int PLANE_A = GM * BRS, PLANE_B = GN * BRS;
@@ -278,11 +337,38 @@ __global__ __launch_bounds__(GT) void k_gemm_bf16x3(const float* __restrict__ A,
 
     StageKC sa, sb;
     StageKM ma, mb;
+    // virtual operand: the rows' coefficient records (8 floats) live in LDS -- VIRT = 1: the tile's GM rows, staged once; VIRT = 2: the 32 rows
+    // of a slab, double-buffered and fetched one slab ahead of the rows themselves (the record of slab i + 2 is requested during slab i, written
+    // to the buffer slab i used while slab i + 1 is converted: every hand-over has a barrier in between)
+    __shared__ __attribute__((aligned(16))) float coef[VIRT == 1 ? GM * 8 : (VIRT == 2 ? 2 * GK * 8 : 4)];
+    int kv = kbeg;                                             // first k of the slab in the stage registers
+    float4 creg = f4zero();
+    auto cload = [&](int k0) {                                 // VIRT = 2: 64 threads fetch the 32 records of slab k0 (clamped)
+        if (VIRT == 2 && t < GK * 2) creg = ld4(pv.scal + (size_t)min(k0 + (t >> 1), max(kend - 1, 0)) * 8 + (t & 1) * 4);
+    };
+    auto cstore = [&](int k0) {
+        if (VIRT == 2 && t < GK * 2) st4(coef + (((k0 - kbeg) / GK) & 1) * (GK * 8) + t * 4, creg);
+    };
+    if (VIRT == 1) {
+        for (int i = t; i < GM * 2; i += GT) st4(coef + i * 4, ld4(pv.scal + (size_t)min(m0 + (i >> 1), M - 1) * 8 + (i & 1) * 4));
+        __syncthreads();
+    }
+    if (VIRT == 2 && kbeg < kend) {
+        cload(kbeg); cstore(kbeg);
+        cload(kbeg + GK); cstore(kbeg + GK);
+        __syncthreads();
+    }
     auto gload = [&](int k0) {
-        if (A_T) load_split_kmajor<GM>(ma, A, lda, m0, M, k0, kend, t); else load_kcontig<GM>(sa, A, lda, m0, M, k0, kend, t);
-        if (B_T) load_kcontig<GN>(sb, B, ldb, n0, N, k0, kend, t); else load_split_kmajor<GN>(mb, B, ldb, n0, N, k0, kend, t);
+        if (A_T) load_split_kmajor<GM>(ma, A, lda, m0, M, k0, kend, t);
+        else if (VIRT == 1) { load_kcontig_virt<GM>(sa, pv, m0, M, k0, t); kv = k0; }
+        else load_kcontig<GM>(sa, A, lda, m0, M, k0, kend, t);
+        if (B_T) load_kcontig<GN>(sb, B, ldb, n0, N, k0, kend, t);
+        else if (VIRT == 2) { load_split_kmajor_virt<GN>(mb, pv, n0, k0, kend, t); kv = k0; cload(k0 + GK); }
+        else load_split_kmajor<GN>(mb, B, ldb, n0, N, k0, kend, t);
     };
     auto lstore = [&]() {
+        if (VIRT == 1) synth_kcontig_virt<GM>(sa, coef, pv, m0, M, kv, t);
+        if (VIRT == 2) synth_kmajor_virt<GN>(mb, coef + (((kv - kbeg) / GK) & 1) * (GK * 8), pv, n0, kv, kend, t);
         if (A_T) store_split_kmajor<GM>(ma, Ahi, Alo, t); else store_split_kcontig<GM>(sa, Ahi, Alo, t);
         if (B_T) store_split_kcontig<GN>(sb, Bhi, Blo, t); else store_split_kmajor<GN>(mb, Bhi, Blo, t);
     };
@@ -321,7 +407,10 @@ __global__ __launch_bounds__(GT) void k_gemm_bf16x3(const float* __restrict__ A,
                 }
         }
         __syncthreads();
-        if (more) lstore();
+        if (more) {
+            lstore();
+            if (VIRT == 2) cstore(k0 + 2 * GK);                // record of slab k0 + 2 GK (requested by gload(k0 + GK)) -> the buffer slab k0 used
+        }
         __syncthreads();
     }
     // ---- epilogue: identical to the fp32 kernel (32x32 patch per wave through LDS, 16-byte row stores) --------------
@@ -706,11 +795,86 @@ int gemm_f32(hipStream_t stream, bool a_t, bool b_t, int64_t M, int64_t N, int64
     return GSAT_OK;
 }
 
+// post_nn of PNAConvSimple on the virtual aggregate: out [N, Ho] = Agg W^T + b (forward) and dW [Ho, NAGG*2*H] = dOut^T Agg (split over
+// the rows, slabs summed in order), both on the split-bf16 tile kernel with the operand loader that recomputes the x_i columns.
+int pna_post_fwd(hipStream_t stream, const PnaVirt& pv, int64_t Nrows, const float* W, int64_t ldw, const float* bias, int64_t Ho, float* out, int64_t ldo) {
+    const int64_t K = (int64_t)pv.NAGG * 2 * pv.H;
+    GSAT_REQUIRE(pv.H % 32 == 0 && Ho % 4 == 0 && ldw % 4 == 0 && ldo % 4 == 0 && Nrows < (1ll << 31), GSAT_ERR_UNSUPPORTED, "gsat_pna_post_fwd: H must be a multiple of 32, Ho of 4");
+    GSAT_REQUIRE(((uintptr_t)W % 16 == 0) && ((uintptr_t)out % 16 == 0) && (!bias || (uintptr_t)bias % 16 == 0) && ((uintptr_t)pv.x % 16 == 0) && ((uintptr_t)pv.aggj % 16 == 0),
+                 GSAT_ERR_ARG, "gsat_pna_post_fwd: operands must be 16-byte aligned");
+    if (Nrows <= 0 || Ho <= 0) return GSAT_OK;
+    xcd_switch_once();
+    const int tn = Ho > 64 ? 2 : 1;
+    dim3 grid((unsigned)ceil_div(Ho, 64 * tn), (unsigned)ceil_div(Nrows, 128), 1);
+    if (tn == 2) k_gemm_bf16x3<false, true, 2, 2, 1><<<grid, GT, 0, stream>>>(nullptr, 0, W, ldw, out, ldo, (int)Nrows, (int)Ho, (int)K, (int)K, bias, 0, 0, pv);
+    else k_gemm_bf16x3<false, true, 2, 1, 1><<<grid, GT, 0, stream>>>(nullptr, 0, W, ldw, out, ldo, (int)Nrows, (int)Ho, (int)K, (int)K, bias, 0, 0, pv);
+    GSAT_LAUNCH_CHECK();
+    return GSAT_OK;
+}
+
+int pna_post_dw(hipStream_t stream, const PnaVirt& pv, int64_t Nrows, const float* dout, int64_t ldd, int64_t Ho, float* dW, int64_t lddw, float* ws,
+                size_t ws_floats) {
+    const int64_t Kc = (int64_t)pv.NAGG * 2 * pv.H;                    // columns of dW
+    GSAT_REQUIRE(pv.H % 64 == 0 && Ho % 4 == 0 && ldd % 4 == 0 && lddw % 4 == 0 && Nrows < (1ll << 31), GSAT_ERR_UNSUPPORTED, "gsat_pna_post_dw: H must be a multiple of 64, Ho of 4");
+    GSAT_REQUIRE(((uintptr_t)dout % 16 == 0) && ((uintptr_t)dW % 16 == 0) && ((uintptr_t)pv.x % 16 == 0) && ((uintptr_t)pv.aggj % 16 == 0), GSAT_ERR_ARG,
+                 "gsat_pna_post_dw: operands must be 16-byte aligned");
+    if (Ho <= 0) return GSAT_OK;
+    xcd_switch_once();
+    const int splits = gemm_splits(Ho, Kc, Nrows, true);
+    const int tm = Ho <= 64 ? 1 : 2, tn = pv.H % 128 == 0 ? 2 : 1;     // a column tile must stay inside one segment of the aggregate
+    dim3 grid((unsigned)ceil_div(Kc, 64 * tn), (unsigned)ceil_div(Ho, 64 * tm), (unsigned)splits);
+    const int kps = (int)(ceil_div(ceil_div(Nrows, splits), GK) * GK);
+    float* o = dW;
+    int64_t ldo = lddw;
+    size_t slab = 0;
+    if (splits > 1) {
+        GSAT_REQUIRE(ws && ws_floats >= (size_t)splits * Ho * Kc, GSAT_ERR_WORKSPACE, "gsat_pna_post_dw: split-K workspace too small");
+        o = ws; ldo = Kc; slab = (size_t)Ho * Kc;
+    }
+#define GO(TM_, TN_) k_gemm_bf16x3<true, false, TM_, TN_, 2><<<grid, GT, 0, stream>>>(dout, ldd, nullptr, 0, o, ldo, (int)Ho, (int)Kc, (int)Nrows, kps, nullptr, 0, slab, pv)
+    if (tm == 2 && tn == 2) GO(2, 2); else if (tm == 2) GO(2, 1); else if (tn == 2) GO(1, 2); else GO(1, 1);
+#undef GO
+    GSAT_LAUNCH_CHECK();
+    if (splits > 1) {
+        k_slab_reduce4<<<(unsigned)ceil_div(Ho * Kc, 256), 256, 0, stream>>>(ws, splits, slab, (int)Ho, (int)Kc, lddw, 0, dW);
+        GSAT_LAUNCH_CHECK();
+    }
+    return GSAT_OK;
+}
+
 }  // namespace gsat
 
 using namespace gsat;
 
 extern "C" {
+
+static int pna_virt_make(const char* who, const float* x, const float* aggj, const float* scal, int64_t H, int nagg, PnaVirt* pv) {
+    GSAT_REQUIRE(x && aggj && scal && (nagg == 4 || nagg == 5) && H > 0 && ((uintptr_t)scal % 16 == 0), GSAT_ERR_ARG, "%s: bad aggregate operand", who);
+    pv->x = x; pv->aggj = aggj; pv->scal = scal; pv->H = (int)H; pv->NAGG = nagg;
+    return GSAT_OK;
+}
+
+int gsat_pna_post_fwd(const float* x, const float* aggj, const float* scal, int64_t N, int64_t H, int num_aggregators,
+                      const float* W, int64_t ldw, const float* bias, int64_t Ho, float* out, void* stream) {
+    PnaVirt pv;
+    int rc = pna_virt_make("gsat_pna_post_fwd", x, aggj, scal, H, num_aggregators, &pv);
+    if (rc) return rc;
+    GSAT_REQUIRE(W && out, GSAT_ERR_ARG, "gsat_pna_post_fwd: null pointer");
+    return pna_post_fwd((hipStream_t)stream, pv, N, W, ldw, bias, Ho, out, Ho);
+}
+
+size_t gsat_pna_post_dw_workspace_floats(int64_t N, int64_t H, int num_aggregators, int64_t Ho) {
+    return gemm_workspace_floats(Ho, (int64_t)num_aggregators * 2 * H, N, true);
+}
+
+int gsat_pna_post_dw(const float* x, const float* aggj, const float* scal, int64_t N, int64_t H, int num_aggregators,
+                     const float* dout, int64_t Ho, float* dW, float* workspace, size_t workspace_floats, void* stream) {
+    PnaVirt pv;
+    int rc = pna_virt_make("gsat_pna_post_dw", x, aggj, scal, H, num_aggregators, &pv);
+    if (rc) return rc;
+    GSAT_REQUIRE(dout && dW, GSAT_ERR_ARG, "gsat_pna_post_dw: null pointer");
+    return pna_post_dw((hipStream_t)stream, pv, N, dout, Ho, Ho, dW, (int64_t)num_aggregators * 2 * H, workspace, workspace_floats);
+}
 
 /* C[M,N] = (accumulate ? C : 0) + op(A) op(B) + bias ; see include/gsat_hip.h */
 int gsat_gemm_f32(int a_t, int b_t, int64_t M, int64_t N, int64_t K, const float* A, int64_t lda, const float* B, int64_t ldb,

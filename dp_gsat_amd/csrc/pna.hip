@@ -10,11 +10,11 @@
 // per-edge gradient row in CSR slot order; (2) per source row, sum those rows through the
 // inverted index (gsat_aggr_sum_fwd with an identity weight).  Both are bitwise reproducible.
 #include "common.h"
+#include "pna_math.h"
 
 namespace gsat {
 
 constexpr int PNA_BLOCK = 128;
-constexpr int AGG_SUM = GSAT_AGG_SUM, AGG_MEAN = GSAT_AGG_MEAN, AGG_MIN = GSAT_AGG_MIN, AGG_MAX = GSAT_AGG_MAX, AGG_VAR = GSAT_AGG_VAR;
 constexpr int SC_AMP = GSAT_SCALE_AMPLIFICATION, SC_ATT = GSAT_SCALE_ATTENUATION, SC_LIN = GSAT_SCALE_LINEAR, SC_INVLIN = GSAT_SCALE_INVERSE_LINEAR;
 
 struct PnaCfg {
@@ -37,58 +37,6 @@ __device__ __forceinline__ float scaler_factor(int s, float deg, float avg_lin, 
         case SC_INVLIN: return deg == 0.f ? 1.f : avg_lin / deg;
         default: return 1.f;
     }
-}
-
-struct Acc4 {   // running per-channel statistics of one float4 column slice of the message
-    float4 s, q, mn, mx;
-    __device__ __forceinline__ void init() {
-        s = f4zero(); q = f4zero();
-        mn = make_float4(INFINITY, INFINITY, INFINITY, INFINITY);
-        mx = make_float4(-INFINITY, -INFINITY, -INFINITY, -INFINITY);
-    }
-    __device__ __forceinline__ void add(float4 m) {
-        s.x += m.x; s.y += m.y; s.z += m.z; s.w += m.w;
-        q.x = fmaf(m.x, m.x, q.x); q.y = fmaf(m.y, m.y, q.y); q.z = fmaf(m.z, m.z, q.z); q.w = fmaf(m.w, m.w, q.w);
-        mn.x = fminf(mn.x, m.x); mn.y = fminf(mn.y, m.y); mn.z = fminf(mn.z, m.z); mn.w = fminf(mn.w, m.w);
-        mx.x = fmaxf(mx.x, m.x); mx.y = fmaxf(mx.y, m.y); mx.z = fmaxf(mx.z, m.z); mx.w = fmaxf(mx.w, m.w);
-    }
-};
-
-// inv_n = 1 / max(count, 1), computed once per row: the per-channel means multiply by it (the reference divides; the two differ by at
-// most one ulp when the count is not a power of two) and the std uses the hardware square root (1 ulp) -- an IEEE division and a
-// correctly rounded sqrt per channel and aggregator were ~330 of the ~450 vector instructions of a row
-__device__ __forceinline__ float agg_value(int a, float s, float q, float mn, float mx, float cnt, float inv_n) {
-    switch (a) {
-        case AGG_SUM: return s;
-        case AGG_MEAN: return s * inv_n;
-        case AGG_MIN: return cnt > 0.f ? mn : 0.f;
-        case AGG_MAX: return cnt > 0.f ? mx : 0.f;
-        default: {
-            float mean = s * inv_n, msq = q * inv_n;
-            float var = msq - mean * mean;
-            return a == AGG_VAR ? var : __builtin_amdgcn_sqrtf(fmaxf(var, 0.f) + 1e-5f);
-        }
-    }
-}
-
-__device__ __forceinline__ float4 agg_value4(int a, const Acc4& c, float cnt) {
-    const float inv_n = 1.f / fmaxf(cnt, 1.f);
-    return make_float4(agg_value(a, c.s.x, c.q.x, c.mn.x, c.mx.x, cnt, inv_n), agg_value(a, c.s.y, c.q.y, c.mn.y, c.mx.y, cnt, inv_n),
-                       agg_value(a, c.s.z, c.q.z, c.mn.z, c.mx.z, cnt, inv_n), agg_value(a, c.s.w, c.q.w, c.mn.w, c.mx.w, cnt, inv_n));
-}
-
-__device__ __forceinline__ float4 f4scale(float a, float4 v) { return make_float4(a * v.x, a * v.y, a * v.z, a * v.w); }
-
-// statistics of (att_k * xi) over the row from the scalar statistics of att
-__device__ __forceinline__ Acc4 self_stats(float4 xi, float sa, float sa2, float amin, float amax) {
-    Acc4 r;
-    r.s = f4scale(sa, xi);
-    r.q = make_float4(xi.x * xi.x * sa2, xi.y * xi.y * sa2, xi.z * xi.z * sa2, xi.w * xi.w * sa2);
-    r.mn = make_float4(xi.x >= 0.f ? xi.x * amin : xi.x * amax, xi.y >= 0.f ? xi.y * amin : xi.y * amax,
-                       xi.z >= 0.f ? xi.z * amin : xi.z * amax, xi.w >= 0.f ? xi.w * amin : xi.w * amax);
-    r.mx = make_float4(xi.x >= 0.f ? xi.x * amax : xi.x * amin, xi.y >= 0.f ? xi.y * amax : xi.y * amin,
-                       xi.z >= 0.f ? xi.z * amax : xi.z * amin, xi.w >= 0.f ? xi.w * amax : xi.w * amin);
-    return r;
 }
 
 // ---- long (hub) rows ----------------------------------------------------------------------------------------------------------
@@ -302,7 +250,10 @@ __global__ __launch_bounds__(PNA_BLOCK) void k_pna_fwd(
     const float* __restrict__ x, const float* __restrict__ att, const float* __restrict__ edge_emb,
     const int32_t* __restrict__ rowptr, const int32_t* __restrict__ col, const int32_t* __restrict__ eid,
     int num_rows, int H, PnaCfg cfg, float* __restrict__ out, int rows_per_group, int c0, int Hc,
-    const int32_t* __restrict__ chunk_ptr, const float* __restrict__ partial) {
+    const int32_t* __restrict__ chunk_ptr, const float* __restrict__ partial, float* __restrict__ scal_out) {
+    // scal_out != NULL (fixed aggregator sets, no edge features): COMPACT output -- `out` is [N, NAGG * H] with the x_j parts only and
+    // scal_out[row] = four coefficients of the row's edge weights; the x_i parts are a closed form of x_i and those four (pna_math.h: PnaVirt), which the
+    // post_nn GEMM's operand loader recomputes instead of reading them back.
     // channels [c0, c0 + Hc) of rows that are H wide: widths above 256 run as one launch per 256-channel chunk
     const LaneGroups<LPR, PNA_BLOCK> lg;
     constexpr int GPB = LaneGroups<LPR, PNA_BLOCK>::GPB;
@@ -382,6 +333,15 @@ __global__ __launch_bounds__(PNA_BLOCK) void k_pna_fwd(
                     }
                 }
             }
+        }
+        if (NAGG && !HAS_EE && scal_out) {
+            if (lane == 0 && c0 == 0) pna_scal_store(scal_out, row, sa, sa2, amin, amax, cnt);
+            if (!on) continue;
+            float* o = out + (size_t)row * ((size_t)(NAGG ? NAGG : 1) * H) + c;
+            constexpr int kAggC[5] = {AGG_MEAN, AGG_MIN, AGG_MAX, GSAT_AGG_STD, AGG_SUM};
+#pragma unroll
+            for (int a = 0; a < (NAGG ? NAGG : 1); ++a) st4(o + (size_t)a * H, agg_value4(kAggC[a], aj, cnt));
+            continue;
         }
         if (!on) continue;
         const Acc4 ai = self_stats(xi, sa, sa2, amin, amax);
@@ -1062,7 +1022,8 @@ extern "C" {
 
 static int pna_fwd_impl(const char* who, const float* x, const float* att, const float* edge_emb, const int32_t* rowptr, const int32_t* col,
                         const int32_t* eid, int64_t N, int64_t E, int64_t H, const int32_t* aggregators, int A, const int32_t* scalers, int S,
-                        float avg_deg_lin, float avg_deg_log, float* out, const int32_t* chunk_ptr, float* partial, hipStream_t stream) {
+                        float avg_deg_lin, float avg_deg_log, float* out, const int32_t* chunk_ptr, float* partial, hipStream_t stream,
+                        float* scal_out = nullptr) {
     GSAT_REQUIRE(N >= 0 && N < (1ll << 31), GSAT_ERR_ARG, "%s: bad N", who);
     PnaCfg cfg;
     int rc = make_cfg(aggregators, A, scalers, S, avg_deg_lin, avg_deg_log, &cfg);
@@ -1073,6 +1034,8 @@ static int pna_fwd_impl(const char* who, const float* x, const float* att, const
     GSAT_REQUIRE(chunk_ptr == nullptr || partial != nullptr, GSAT_ERR_ARG, "%s: chunk_ptr needs the record workspace", who);
     if (E <= CH) chunk_ptr = nullptr;                      // no row can be long
     const int nagg = fixed_aggregators(cfg);
+    GSAT_REQUIRE(!scal_out || (nagg && !edge_emb && !chunk_ptr), GSAT_ERR_UNSUPPORTED,
+                 "%s: the compact output needs (mean,min,max,std[,sum]) with the identity scaler, no edge features, no hub chunks", who);
     for (int c0 = 0; c0 < (int)H; c0 += PNA_CHUNK) {
         const int Hc = std::min<int>(PNA_CHUNK, (int)H - c0);
         const int lpr = pna_lpr(Hc);
@@ -1082,8 +1045,8 @@ static int pna_fwd_impl(const char* who, const float* x, const float* att, const
         const int cb = chunk_ptr ? (int)std::min<int64_t>(ceil_div(pna_max_chunks(E), gpb), 256 * 16) : 0;
 #define GO(L, EE, NA)                                                                                                                       \
     do {                                                                                                                                    \
-        k_pna_fwd<L, EE, NA, false><<<nb, PNA_BLOCK, 0, stream>>>(x, att, edge_emb, rowptr, col, eid, (int)N, (int)H, cfg, out, rpg, c0, Hc, chunk_ptr, partial); \
-        if (cb) k_pna_fwd<L, EE, NA, true><<<cb, PNA_BLOCK, 0, stream>>>(x, att, edge_emb, rowptr, col, eid, (int)N, (int)H, cfg, out, rpg, c0, Hc, chunk_ptr, partial); \
+        k_pna_fwd<L, EE, NA, false><<<nb, PNA_BLOCK, 0, stream>>>(x, att, edge_emb, rowptr, col, eid, (int)N, (int)H, cfg, out, rpg, c0, Hc, chunk_ptr, partial, scal_out); \
+        if (cb) k_pna_fwd<L, EE, NA, true><<<cb, PNA_BLOCK, 0, stream>>>(x, att, edge_emb, rowptr, col, eid, (int)N, (int)H, cfg, out, rpg, c0, Hc, chunk_ptr, partial, scal_out); \
     } while (0)
 #define CALL(L)                                                                                                              \
     do {                                                                                                                     \
@@ -1116,6 +1079,14 @@ int gsat_pna_fwd_node_att(const float* x, const float* node_att, const int32_t* 
     GSAT_REQUIRE(node_att, GSAT_ERR_ARG, "gsat_pna_fwd_node_att: null node attention");
     return pna_fwd_impl("gsat_pna_fwd_node_att", x, node_att, nullptr, rowptr, col, /*eid=*/nullptr, N, 0, H, aggregators, A, scalers, S,
                         avg_deg_lin, avg_deg_log, out, nullptr, nullptr, (hipStream_t)stream_);
+}
+
+int gsat_pna_fwd_compact(const float* x, const float* att, const int32_t* rowptr, const int32_t* col, const int32_t* eid, int64_t N,
+                         int64_t H, const int32_t* aggregators, int A, float* aggj, float* scal, void* stream_) {
+    GSAT_REQUIRE(aggj && scal && ((uintptr_t)scal % 16 == 0), GSAT_ERR_ARG, "gsat_pna_fwd_compact: null / misaligned output");
+    const int32_t ident = 0;
+    return pna_fwd_impl("gsat_pna_fwd_compact", x, att, nullptr, rowptr, col, eid, N, 0, H, aggregators, A, &ident, 1, 1.f, 1.f, aggj, nullptr,
+                        nullptr, (hipStream_t)stream_, scal);
 }
 
 size_t gsat_pna_long_row_floats(int64_t num_edges, int64_t H, int has_edge_emb) {

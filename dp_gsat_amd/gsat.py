@@ -13,7 +13,7 @@ import torch.nn as nn
 
 from .get_model import MLP
 from .graph_index import get_index, sync_free
-from .ops import ExtractorAttention, InfoLoss, Lift, LiftedAttention, Sample, Symmetrise, new_seed
+from .ops import ExtractorAttention, InfoLoss, Lift, LiftedAttention, Sample, Symmetrise, edge_tensor, new_seed
 
 
 class ExtractorMLP(nn.Module):
@@ -126,7 +126,7 @@ def symmetrise_edge_att(att, edge_index, num_nodes):
 
 def info_loss(att, r):
     """example/gsat.py:31 ; src/run_gsat.py:127,132 (tensor prior allowed, detached)."""
-    return InfoLoss.apply(att, r)
+    return InfoLoss.apply(edge_tensor(att), edge_tensor(r))
 
 
 class GSAT(nn.Module):

@@ -17,6 +17,9 @@ from .graph_index import BatchIndex
 def _f32c(t: Optional[torch.Tensor]) -> Optional[torch.Tensor]:
     if t is None:
         return None
+    if isinstance(t, LiftedAttention):
+        # inside Function.forward autograd is off: writing the tensor out here would silently cut node_att from the graph
+        raise TypeError("LiftedAttention reached an autograd Function: pass dp_gsat_amd.ops.edge_tensor(att) instead")
     if t.dtype != torch.float32:
         raise TypeError("dp_gsat_amd kernels compute in fp32; got " + str(t.dtype))
     return t.contiguous()
@@ -68,6 +71,12 @@ class LiftedAttention:
 
     def __repr__(self):
         return f"LiftedAttention(nodes={self.index.N}, edges={self.index.E}, materialised={self._edge is not None})"
+
+
+def edge_tensor(att):
+    """The [E, 1] tensor of an attention value: ``att.edge()`` for the lazy lifted view, ``att`` itself otherwise.  Call it (under autograd)
+    before handing attention to a custom autograd Function."""
+    return att.edge() if isinstance(att, LiftedAttention) else att
 
 
 def _forward_operator(name):
@@ -789,6 +798,117 @@ class LinearFn(torch.autograd.Function):
             _gemm(1, 0, n_out, n_in, rows, dy, n_out, x, n_in, dw, n_in, split=big)
         db = colsum(dy) if ctx.has_bias and ctx.needs_input_grad[2] else None
         return dx, dw, db
+
+
+class PnaConvFn(torch.autograd.Function):
+    """PNAConvSimple.forward = post_nn(aggregate(message)) (src/models/conv_layers.py:148-153) as ONE autograd node on the compact
+    aggregate: the forward writes the x_j parts [N, A*H] + four scalars per row (gsat_pna_fwd_compact) and the post_nn GEMM rebuilds the
+    x_i columns in its operand loader (gsat_pna_post_fwd); the backward takes dW the same way (gsat_pna_post_dw), forms dAgg = dout W
+    once and hands it to the one-launch aggregation backward.  Saves half of the [N, A*2*H] write + read per layer pass and half of the
+    saved activation.  Edge weights: none, an [E] tensor, or node attention formed inside the kernels."""
+
+    @staticmethod
+    def forward(ctx, x, att, node_att, weight, bias, index: BatchIndex, aggr_codes):
+        import ctypes
+        x, weight = _f32c(x), _f32c(weight)
+        bias = None if bias is None else _f32c(bias)
+        N, H = x.shape
+        A, Ho = len(aggr_codes), weight.shape[0]
+        if N != index.N:
+            raise ValueError(f"x has {N} rows but the index was built for {index.N} nodes")
+        if node_att is not None:
+            if node_att.numel() != N:
+                raise ValueError("node attention must have one entry per node")
+            w, eid = _f32c(node_att).view(-1), None
+        elif att is not None:
+            w, eid = _flat_att(att, index.E), index.eid_by_dst
+        else:
+            w, eid = None, None
+        a_arr = (ctypes.c_int32 * A)(*aggr_codes)
+        dev, f32 = x.device, torch.float32
+        aggj = torch.empty(N, A * H, dtype=f32, device=dev)
+        scal = torch.empty(N, 8, dtype=f32, device=dev)
+        call("gsat_pna_fwd_compact", ptr(x), ptr(w), ptr(index.rowptr_dst), ptr(index.src_by_dst), ptr(eid), N, H, a_arr, A, ptr(aggj), ptr(scal),
+             stream())
+        out = torch.empty(N, Ho, dtype=f32, device=dev)
+        call("gsat_pna_post_fwd", ptr(x), ptr(aggj), ptr(scal), N, H, A, ptr(weight), weight.shape[1], ptr(bias), Ho,
+             ptr(out), stream())
+        ctx.save_for_backward(x, w if w is not None else x.new_empty(0), aggj, scal, weight)
+        ctx.index, ctx.aggr = index, tuple(aggr_codes)
+        ctx.mode = "node" if node_att is not None else ("edge" if att is not None else "none")
+        ctx.att_shape = node_att.shape if node_att is not None else (att.shape if att is not None else None)
+        ctx.has_bias = bias is not None
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        import ctypes
+        from ._lib import load
+        x, w, aggj, scal, weight = ctx.saved_tensors
+        index, aggr_codes = ctx.index, ctx.aggr
+        dout = _f32c(dout)
+        N, H = x.shape
+        A, Ho = len(aggr_codes), weight.shape[0]
+        F = A * 2 * H
+        dev, f32 = x.device, torch.float32
+        a_arr = (ctypes.c_int32 * A)(*aggr_codes)
+        s_arr = (ctypes.c_int32 * 1)(0)
+        dW = db = None
+        if ctx.needs_input_grad[3]:
+            dW = torch.empty_like(weight)
+            wsf = int(load().gsat_pna_post_dw_workspace_floats(N, H, A, Ho))
+            ws = torch.empty(wsf, dtype=f32, device=dev) if wsf else None
+            call("gsat_pna_post_dw", ptr(x), ptr(aggj), ptr(scal), N, H, A, ptr(dout), Ho, ptr(dW), ptr(ws), wsf, stream())
+        if ctx.has_bias and ctx.needs_input_grad[4]:
+            db = colsum(dout)
+        need_x = ctx.needs_input_grad[0]
+        need_att = ctx.needs_input_grad[2] if ctx.mode == "node" else (ctx.needs_input_grad[1] if ctx.mode == "edge" else False)
+        if not (need_x or need_att):
+            return None, None, None, dW, db, None, None
+        dagg = torch.empty(N, F, dtype=f32, device=dev)
+        _gemm(0, 0, N, F, Ho, dout, Ho, weight, F, dagg, F)
+        tile_ptr, T, rows_nominal, rows_cap, edges_cap, spill = index.pna_tiles(H)
+        dmsg = torch.empty(max(index.E, 1), H, dtype=f32, device=dev)[: index.E]
+        dx = torch.empty_like(x)
+        datt = dna = None
+        if ctx.mode == "node":
+            dna = torch.empty(N, dtype=f32, device=dev) if need_att else None
+            dw = torch.empty(max(index.E, 1), dtype=f32, device=dev) if need_att else None
+            call("gsat_pna_bwd_tiled_node_att", ptr(x), ptr(w), ptr(dagg), ptr(index.rowptr_dst), ptr(index.src_by_dst), ptr(tile_ptr), T,
+                 rows_nominal, rows_cap, edges_cap, ptr(index.rowptr_src), ptr(index.slot_dst_of_srcslot), N, index.E, H, a_arr, A, s_arr, 1,
+                 ptr(spill[1:]), ptr(spill[:1]), ptr(dx), ptr(dmsg), ptr(dna), ptr(dw), stream())
+            dna = dna.view(ctx.att_shape) if need_att else None
+        else:
+            datt = torch.empty(index.E, dtype=f32, device=dev) if need_att else None
+            call("gsat_pna_bwd_tiled", ptr(x), ptr(w) if ctx.mode == "edge" else None, ptr(dagg), ptr(index.rowptr_dst), ptr(index.src_by_dst),
+                 ptr(index.eid_by_dst), ptr(tile_ptr), T, rows_nominal, rows_cap, edges_cap, ptr(index.rowptr_src),
+                 ptr(index.slot_dst_of_srcslot), N, index.E, H, a_arr, A, s_arr, 1, ptr(spill[1:]), ptr(spill[:1]), ptr(dx), ptr(dmsg),
+                 ptr(datt), stream())
+            datt = datt.view(ctx.att_shape) if need_att else None
+        return dx, datt, dna, dW, db, None, None
+
+
+def pna_conv(x, index, att, edge_emb, aggregators, scalers, avg_deg, weight, bias):
+    """post_nn[0](pna_aggregate(...)) for a PNAConvSimple whose post_nn is one Linear, on the compact aggregate -- opt-in
+    (GSAT_PNA_COMPACT=1): measured on MI355X at C3 (profiles/r03_summary.md) the aggregation forward drops from 45 to 24 us per layer
+    pass, but the post_nn GEMMs, whose split-bf16 staging is already vector-ALU bound, pay more for rebuilding the x_i columns (forward 57
+    -> 87 us, weight gradient 79 -> 96 us) than the halved traffic returns: whole step 4.69 vs 4.55 ms.  Returns None when not taken (the
+    caller runs the two ops)."""
+    a = [AGGREGATOR_CODES[k] for k in aggregators]
+    s = [SCALER_CODES[k] for k in scalers]
+    N, H = x.shape
+    if not (x.is_cuda and N > 0 and edge_emb is None and _FIXED_PNA.get((tuple(a), tuple(s))) and H % 64 == 0 and H <= 256
+            and weight.shape[1] == len(a) * 2 * H and weight.shape[0] % 4 == 0 and os.environ.get("GSAT_PNA_COMPACT", "0") == "1"
+            and os.environ.get("GSAT_PNA_TILED", "1") != "0" and index.long_rows_nowait[0] is None
+            and (bias is None or bias.data_ptr() % 16 == 0) and index.pna_tiles(H)):
+        return None
+    node_att = None
+    if isinstance(att, LiftedAttention):
+        if att.index is index and att._edge is None and os.environ.get("GSAT_NODE_ATT_LIFT", "0") != "1":
+            node_att, att = att.node_att, None
+        else:
+            att = att.edge()
+    return PnaConvFn.apply(x, att, node_att, weight, bias, index, a)
 
 
 def linear(x, weight, bias=None):

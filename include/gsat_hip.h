@@ -263,6 +263,27 @@ int gsat_pna_bwd_tiled(const float* x, const float* att, const float* dout, cons
  *                                 (bitwise reproducible); dw [E] is scratch for the spilled edges' shares (needed when dnode_att != NULL).
  * replaces: GSAT.lift_node_att_to_edge_att + its autograd backward fused into PNAConvSimple's aggregation (src/models/pna.py:57-59).
  */
+/*
+ * PNAConvSimple without the x_i half of the aggregate (src/models/conv_layers.py:148-153 post_nn(aggregate(message))).  The x_i part of
+ * the message is the same vector for every in-edge of a row, so its aggregates are a closed form of x_i and four statistics of the row's
+ * edge weights; the [N, A*2*H] aggregate is therefore never written: the forward emits the x_j parts and the four scalars, and the post_nn
+ * GEMMs rebuild the x_i columns in their operand loader (the arithmetic of gsat_pna_fwd up to the order of two multiplications).
+ *   gsat_pna_fwd_compact:  aggj [N, A*H] (aggregator-major), scal [N,8] = (sum a / n, sum a^2 / n, min a, max a, sum a, 0, 0, 0) of the row's
+ *                          edge weights, n = max(in-degree, 1), min / max stored as 0 for a row without in-edges.  att NULL: unit weights;
+ *                          att [E] with eid; att = node attention [N] with eid NULL (as gsat_pna_fwd_node_att).  Aggregators
+ *                          (mean,min,max,std[,sum]), identity scaler, no edge features.
+ *   gsat_pna_post_fwd:     out [N, Ho] = Agg W^T + bias, W [Ho, A*2*H] row-major (nn.Linear), split-bf16 x 3 MFMA.  H % 32 == 0.
+ *   gsat_pna_post_dw:      dW [Ho, A*2*H] = dout^T Agg, reduced over the rows in ordered slabs (workspace: *_workspace_floats).  H % 64 == 0.
+ * The backward's dAgg = dout W stays a plain GEMM into [N, A*2*H] (gsat_gemm_bf16x3) and feeds gsat_pna_bwd_tiled[_node_att].
+ */
+int gsat_pna_fwd_compact(const float* x, const float* att, const int32_t* rowptr, const int32_t* col, const int32_t* eid, int64_t num_rows,
+                         int64_t H, const int32_t* aggregators, int num_aggregators, float* aggj, float* scal, void* stream);
+int gsat_pna_post_fwd(const float* x, const float* aggj, const float* scal, int64_t num_rows, int64_t H,
+                      int num_aggregators, const float* W, int64_t ldw, const float* bias, int64_t Ho, float* out, void* stream);
+size_t gsat_pna_post_dw_workspace_floats(int64_t num_rows, int64_t H, int num_aggregators, int64_t Ho);
+int gsat_pna_post_dw(const float* x, const float* aggj, const float* scal, int64_t num_rows, int64_t H,
+                     int num_aggregators, const float* dout, int64_t Ho, float* dW, float* workspace, size_t workspace_floats, void* stream);
+
 int gsat_pna_fwd_node_att(const float* x, const float* node_att, const int32_t* rowptr, const int32_t* col, int64_t num_rows, int64_t H,
                           const int32_t* aggregators, int num_aggregators, const int32_t* scalers, int num_scalers, float avg_deg_lin,
                           float avg_deg_log, float* out, void* stream);

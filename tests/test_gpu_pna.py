@@ -194,6 +194,7 @@ def test_pna_node_attention_without_lift(dev, monkeypatch, H, lds_budget, aligne
     from dp_gsat_amd.graph_index import BatchIndex
     from dp_gsat_amd.ops import LiftedAttention, PnaAggregate, pna_aggregate
     monkeypatch.setenv("GSAT_PNA_TILE_LDS", str(lds_budget))
+    monkeypatch.setattr("dp_gsat_amd.graph_index._HUBS_SEEN", [False])      # (an earlier test's hub rows would route this batch to the chunked path until its status lands)
     ei, batch, N = random_batch(17 + H, 24, 1, 40)
     hub = torch.arange(1, 200)
     star = torch.stack([torch.cat([hub, torch.zeros_like(hub)]), torch.cat([torch.zeros_like(hub), hub])]) + (N - 200 if N > 400 else 0)
@@ -301,3 +302,71 @@ def test_pna_tiled_backward_under_back_to_back_graph_replays(dev):
     finally:
         G.set_sync_free(False)
         G.clear_cache()
+
+
+@pytest.mark.parametrize("H,Ho", [(64, 64), (128, 128), (128, 32), (256, 64)])
+@pytest.mark.parametrize("mode", ["none", "edge", "node"])
+def test_pna_conv_on_the_compact_aggregate(dev, monkeypatch, H, Ho, mode):
+    """PNAConvSimple with one post_nn Linear as one autograd node on the compact aggregate (gsat_pna_fwd_compact + gsat_pna_post_fwd /
+    _dw: the x_i half of [N, A*2*H] is rebuilt in the GEMM's operand loader) vs the two-op path (aggregate, then Linear) and vs the oracle
+    (src/models/conv_layers.py:148-153,163-185): unit weights, an [E,1] attention tensor, lifted node attention; isolated nodes and rows
+    without in-edges; bitwise reproducible."""
+    from dp_gsat_amd.conv_layers import PNAConvSimple
+    from dp_gsat_amd.graph_index import BatchIndex
+    from dp_gsat_amd.ops import LiftedAttention
+    monkeypatch.setattr("dp_gsat_amd.graph_index._HUBS_SEEN", [False])
+    ei, batch, N = random_batch(5 + H + Ho, 40, 1, 40)
+    ei = shuffle_edges(ei, 3)
+    E = ei.shape[1]
+    g = torch.Generator().manual_seed(H + Ho)
+    x = torch.randn(N, H, generator=g)
+    x[::5] = x[::5].relu()
+    att = torch.rand(E, 1, generator=g)
+    na = torch.rand(N, 1, generator=g)
+    aggr = ["mean", "min", "max", "std"]
+    deg = torch.bincount(torch.bincount(ei[1], minlength=N))
+    conv = PNAConvSimple(2 * H, Ho, aggr, ["identity"], deg, post_layers=1)
+    W, b = conv.post_nn[0].weight.detach().clone(), conv.post_nn[0].bias.detach().clone()
+    go = torch.randn(N, Ho, generator=g)
+    avg = {"lin": 1.0, "log": 1.0}
+    ref = {}
+    for dt in (torch.float32, torch.float64):
+        xo = x.to(dt).clone().requires_grad_(True)
+        ao = (att if mode == "edge" else na).to(dt).clone().requires_grad_(True)
+        wo, bo = W.to(dt).clone().requires_grad_(True), b.to(dt).clone().requires_grad_(True)
+        w_e = None if mode == "none" else (ao if mode == "edge" else oops.lift_node_att_to_edge_att(ao, ei))
+        out = oops.pna_aggregate(xo, ei, w_e, aggr, ["identity"], avg) @ wo.t() + bo
+        out.backward(go.to(dt))
+        ref[dt] = (out.detach(), xo.grad, None if mode == "none" else ao.grad, wo.grad, bo.grad)
+
+    conv = conv.to(dev)
+    from dp_gsat_amd import _lib
+    calls, real = [], _lib.call
+    monkeypatch.setattr("dp_gsat_amd.ops.call", lambda name, *a: (calls.append(name), real(name, *a))[1])
+
+    def run(compact):
+        monkeypatch.setenv("GSAT_PNA_COMPACT", "1" if compact else "0")
+        ix = BatchIndex(ei.to(dev), N)
+        ix.graphs(batch.to(dev))
+        xd = x.to(dev).requires_grad_(True)
+        ad = None if mode == "none" else (att if mode == "edge" else na).to(dev).requires_grad_(True)
+        w_e = None if mode == "none" else (ad if mode == "edge" else LiftedAttention(ad, ix))
+        conv.zero_grad(set_to_none=True)
+        calls.clear()
+        out = conv(xd, ei.to(dev), None, edge_atten=w_e, index=ix)
+        out.backward(go.to(dev))
+        return (out.detach(), xd.grad, None if ad is None else ad.grad, conv.post_nn[0].weight.grad.clone(), conv.post_nn[0].bias.grad.clone()), list(calls)
+
+    got, names = run(True)
+    assert names[:2] == ["gsat_pna_fwd_compact", "gsat_pna_post_fwd"] and "gsat_pna_post_dw" in names and "gsat_pna_fwd" not in names, names
+    for a, r32, r64, what in zip(got, ref[torch.float32], ref[torch.float64], ("out", "dx", "datt", "dW", "db")):
+        if a is not None:
+            close(a, r32, 3e-5, ref64=r64, what=what)          # (split-bf16 products: ~1e-5 of the result's scale)
+    again, _ = run(True)
+    for a, b_ in zip(got, again):
+        assert a is None or torch.equal(a, b_)                                                     # bitwise reproducible
+    two, names2 = run(False)
+    assert "gsat_pna_fwd_compact" not in names2
+    for a, b_, what in zip(got, two, ("out", "dx", "datt", "dW", "db")):
+        if a is not None:
+            close(a, b_, 3e-5, what=what + ": compact vs two-op path")
