@@ -575,6 +575,131 @@ __global__ __launch_bounds__(WS_THREADS, (KR <= 64 && NQ <= 4) ? 4 : 2) void k_g
     }
 }
 
+// ================================================================================================================
+// The same weight-stationary scheme on the split-bf16 path (hi*hi + hi*lo + lo*hi, 32x32x16 bf16 MFMA) for the BACKWARD-data products of
+// the extractor (da1 = dh2 W2, demb = dh1 W1: 51 639 x 256 x 128 and 51 639 x 128 x 256 at C3).  On the 128 x 128 tile kernel these run
+// 28-30 us against a ~16 us floor for their 79 MB of operands: four K-slabs per tile, a prologue and an epilogue per tile.  Here a
+// persistent workgroup keeps its share of B as bf16 hi / lo fragments in registers (wave w: column block w % NB, k-split w / NB; KSTEPS
+// 16-deep steps = 8 KSTEPS registers) and streams 32-row tiles of A: the staging threads split each fp32 value ONCE into the two bf16
+// planes of a double-buffered LDS image, every wave then reads its operand fragments with one ds_read_b128 per plane and step.  The MFMA
+// time is a quarter of the fp32 kernel's, so the launch is bound by its HBM traffic.  k-splits meet in LDS in fixed order.
+// ================================================================================================================
+template <bool B_T, int KSTEPS, int NQ>
+__global__ __launch_bounds__(WS_THREADS, 2) void k_gemm_ws_x3(const float* __restrict__ A, int64_t lda, const float* __restrict__ B, int64_t ldb,
+                                                             float* __restrict__ C, int64_t ldc, int M, int N, int K, int NB, int accumulate, int tiles) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char wx_lds[];
+    const int RS = 2 * K + 16;                               // bytes per row of one plane
+    const int PLANE = WS_ROWS * RS;
+    unsigned char* const buf0 = wx_lds;                      // [hi plane | lo plane]
+    unsigned char* const buf1 = wx_lds + 2 * PLANE;
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const int cb = wave % NB, ks = wave / NB, KS = 8 / NB;
+    const int c = lane & 31, h = lane >> 5;
+    const int n0 = blockIdx.y * (NB * 32) + cb * 32;
+    const int kw0 = ks * (KSTEPS * 16);                      // first k of this wave's range
+    // ---- this wave's share of B -> hi / lo fragments in registers (once): lane (c, h) holds k = kw0 + 16 s + 8 h + j of column n0 + c ----
+    bf16x8 bh[KSTEPS], bl[KSTEPS];
+    {
+        const int col = min(n0 + c, N - 1);
+#pragma unroll
+        for (int s_ = 0; s_ < KSTEPS; ++s_) {
+            float v[8];
+            const int k0 = kw0 + 16 * s_ + 8 * h;
+            if (B_T) {
+                const float4 v0 = ld4(B + (size_t)col * ldb + k0), v1 = ld4(B + (size_t)col * ldb + k0 + 4);
+                v[0] = v0.x; v[1] = v0.y; v[2] = v0.z; v[3] = v0.w; v[4] = v1.x; v[5] = v1.y; v[6] = v1.z; v[7] = v1.w;
+            } else {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) v[j] = B[(size_t)(k0 + j) * ldb + col];
+            }
+            uint4 H = make_uint4(pack_bf16(v[0], v[1]), pack_bf16(v[2], v[3]), pack_bf16(v[4], v[5]), pack_bf16(v[6], v[7]));
+            uint4 L = make_uint4(pack_bf16(v[0] - bf16_hi(v[0]), v[1] - bf16_hi(v[1])), pack_bf16(v[2] - bf16_hi(v[2]), v[3] - bf16_hi(v[3])),
+                                 pack_bf16(v[4] - bf16_hi(v[4]), v[5] - bf16_hi(v[5])), pack_bf16(v[6] - bf16_hi(v[6]), v[7] - bf16_hi(v[7])));
+            bh[s_] = *reinterpret_cast<bf16x8*>(&H);
+            bl[s_] = *reinterpret_cast<bf16x8*>(&L);
+        }
+    }
+    // ---- A tile staging: 32 x K floats = NQ float4 per thread, split into the two planes at the LDS store ----
+    const int K4 = K >> 2;
+    int srow[NQ], soff[NQ];
+#pragma unroll
+    for (int p = 0; p < NQ; ++p) {
+        const int idx = t + p * WS_THREADS;
+        srow[p] = idx / K4;
+        soff[p] = 4 * (idx % K4);
+    }
+    float4 st[NQ];
+    auto gload = [&](int tile) {
+        const int m0 = tile * WS_ROWS;
+#pragma unroll
+        for (int p = 0; p < NQ; ++p) st[p] = ld4(A + (size_t)min(m0 + srow[p], M - 1) * lda + soff[p]);       // rows past M: clamped, never stored
+    };
+    auto lstore = [&](unsigned char* dst) {
+#pragma unroll
+        for (int p = 0; p < NQ; ++p) {
+            const float4 v = st[p];
+            const uint2 H = make_uint2(pack_bf16(v.x, v.y), pack_bf16(v.z, v.w));
+            const uint2 L = make_uint2(pack_bf16(v.x - bf16_hi(v.x), v.y - bf16_hi(v.y)), pack_bf16(v.z - bf16_hi(v.z), v.w - bf16_hi(v.w)));
+            *reinterpret_cast<uint2*>(dst + srow[p] * RS + soff[p] * 2) = H;
+            *reinterpret_cast<uint2*>(dst + PLANE + srow[p] * RS + soff[p] * 2) = L;
+        }
+    };
+    int tile = blockIdx.x;
+    if (tile < tiles) { gload(tile); lstore(buf0); }
+    __builtin_amdgcn_s_waitcnt(0x0F70);                      // vmcnt(0): B is in registers now (see k_gemm_ws)
+    __syncthreads();
+    unsigned char* cur = buf0;
+    unsigned char* nxt = buf1;
+    const bool col_ok = n0 + c < N;
+    for (; tile < tiles; tile += gridDim.x) {
+        const int ntile = tile + gridDim.x;
+        if (ntile < tiles) gload(ntile);
+        f32x16 acc;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+        const unsigned char* arow = cur + c * RS + (kw0 + 8 * h) * 2;
+#pragma unroll
+        for (int s_ = 0; s_ < KSTEPS; ++s_) {
+            const bf16x8 ah = *reinterpret_cast<const bf16x8*>(arow + 32 * s_);
+            const bf16x8 al = *reinterpret_cast<const bf16x8*>(arow + PLANE + 32 * s_);
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh[s_], acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl[s_], acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh[s_], acc, 0, 0, 0);
+        }
+        float* const xch = reinterpret_cast<float*>(cur);
+        if (KS > 1) {
+            __syncthreads();                                 // every wave is done reading `cur`: it becomes the exchange buffer
+            if (ks > 0) {
+                float* part = xch + ((ks - 1) * NB + cb) * 1024;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) part[r * 64 + lane] = acc[r];
+            }
+        }
+        if (ntile < tiles) lstore(nxt);
+        __syncthreads();
+        if (ks == 0) {
+            if (KS > 1) {
+                for (int s2 = 1; s2 < KS; ++s2) {            // fixed order: bitwise reproducible
+                    const float* part = xch + ((s2 - 1) * NB + cb) * 1024;
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) acc[r] += part[r * 64 + lane];
+                }
+            }
+            const int m0 = tile * WS_ROWS;
+            float* crow = C + (size_t)(m0 + 4 * h) * ldc + n0 + c;
+            if (col_ok) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int rr = (r & 3) + 8 * (r >> 2);
+                    if (m0 + 4 * h + rr < M) crow[(size_t)rr * ldc] = accumulate ? crow[(size_t)rr * ldc] + acc[r] : acc[r];
+                }
+            }
+        }
+        if (KS > 1) __syncthreads();
+        unsigned char* tmp = cur; cur = nxt; nxt = tmp;
+    }
+}
+
 // out[i] = (accumulate ? out[i] : 0) + sum_s slabs[s][i].  Eight independent partial sums (slab s goes to
 // partial s % 8) keep eight loads in flight; the order is fixed, so the result is bitwise reproducible.
 __global__ void k_slab_reduce(const float* __restrict__ slabs, int nslab, size_t slab_stride, int M, int N, int64_t ldc,
@@ -735,6 +860,55 @@ static int gemm_ws(hipStream_t stream, bool b_t, int64_t M, int64_t N, int64_t K
     GSAT_REQUIRE(false, GSAT_ERR_UNSUPPORTED, "gemm_ws: K = %lld is not 64, 128, 256 or 512", (long long)K);
 }
 
+// ---- weight-stationary split-bf16 dispatch ------------------------------------------------------------------------
+static bool wsx3_geometry(int64_t N, int64_t K, int* nb, int* ksteps) {
+    if (N % 32 != 0 || N > 256 || (K != 64 && K != 128 && K != 256 && K != 512)) return false;
+    const int64_t NB = N / 32;
+    if (NB != 1 && NB != 2 && NB != 4 && NB != 8) return false;
+    const int64_t KS = 8 / NB, Kw = K / KS;
+    if (Kw % 16 != 0) return false;
+    const int64_t st = Kw / 16;
+    if (st != 2 && st != 4 && st != 8) return false;                          // 16 / 32 / 64 fragment registers
+    if ((KS - 1) * NB * 4096 > 2 * WS_ROWS * (2 * K + 16)) return false;      // the k-split exchange must fit one A buffer
+    *nb = (int)NB; *ksteps = (int)st;
+    return true;
+}
+static bool wsx3_applicable(int64_t M, int64_t N, int64_t K) {
+    static const int on = getenv("GSAT_GEMM_WSX3") ? atoi(getenv("GSAT_GEMM_WSX3")) : 1;
+    int nb, st;
+    return on && M >= 8192 && M < (1ll << 31) - 64 && wsx3_geometry(N, K, &nb, &st);
+}
+template <bool B_T, int KSTEPS, int NQ>
+static int wsx3_launch(hipStream_t stream, dim3 grid, size_t lds, const float* A, int64_t lda, const float* B, int64_t ldb, float* C, int64_t ldc,
+                       int M, int N, int K, int nb, int accumulate, int tiles) {
+    static size_t allowed = 64 * 1024;
+    if (lds > allowed) {
+        GSAT_CHECK_HIP(hipFuncSetAttribute((const void*)k_gemm_ws_x3<B_T, KSTEPS, NQ>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        allowed = lds;
+    }
+    k_gemm_ws_x3<B_T, KSTEPS, NQ><<<grid, WS_THREADS, lds, stream>>>(A, lda, B, ldb, C, ldc, M, N, K, nb, accumulate, tiles);
+    GSAT_LAUNCH_CHECK();
+    return GSAT_OK;
+}
+static int gemm_wsx3(hipStream_t stream, bool b_t, int64_t M, int64_t N, int64_t K, const float* A, int64_t lda, const float* B, int64_t ldb,
+                     float* C, int64_t ldc, bool accumulate) {
+    int nb = 0, st = 0;
+    GSAT_REQUIRE(wsx3_geometry(N, K, &nb, &st), GSAT_ERR_UNSUPPORTED, "gemm_wsx3: unsupported shape");
+    const int tiles = (int)ceil_div(M, WS_ROWS);
+    const size_t lds = (size_t)4 * WS_ROWS * (2 * K + 16);
+    const int nq = (int)(K / 64);
+    const int per_cu = (2 * lds <= 150 * 1024 && st * 8 + nq * 9 <= 84) ? 2 : 1;      // two workgroups per CU need <= 128 registers (fragments + staging)
+    const dim3 grid((unsigned)std::min<int64_t>(tiles, (int64_t)256 * per_cu), 1);
+#define XGO(BT, S, Q) return wsx3_launch<BT, S, Q>(stream, grid, lds, A, lda, B, ldb, C, ldc, (int)M, (int)N, (int)K, nb, accumulate ? 1 : 0, tiles)
+#define XQ(BT, S) do { switch (nq) { case 1: XGO(BT, S, 1); case 2: XGO(BT, S, 2); case 4: XGO(BT, S, 4); case 8: XGO(BT, S, 8); default: break; } } while (0)
+#define XS(BT) do { switch (st) { case 2: XQ(BT, 2); break; case 4: XQ(BT, 4); break; default: XQ(BT, 8); break; } } while (0)
+    if (b_t) XS(true); else XS(false);
+#undef XS
+#undef XQ
+#undef XGO
+    GSAT_REQUIRE(false, GSAT_ERR_UNSUPPORTED, "gemm_wsx3: K = %lld is not 64, 128, 256 or 512", (long long)K);
+}
+
 // C[M,N] (+)= op(A) op(B) (+ bias).  a_t: A given as [K,M]; b_t: B given as [N,K].  K % 4 == 0 and the
 // contiguous extents must be multiples of 4 (float4 staging).  `ws` is needed when gemm_splits() > 1.
 int gemm_f32(hipStream_t stream, bool a_t, bool b_t, int64_t M, int64_t N, int64_t K, const float* A, int64_t lda, const float* B,
@@ -748,6 +922,7 @@ int gemm_f32(hipStream_t stream, bool a_t, bool b_t, int64_t M, int64_t N, int64
                  GSAT_ERR_ARG, "gemm_f32: operands, output and bias must be 16-byte aligned with ldc % 4 == 0");
     const bool split = use_bf16x3(M, N, K, allow_split);
     if (!a_t && !split && !accumulate && ws_applicable(M, N, K)) return gemm_ws(stream, b_t, M, N, K, A, lda, B, ldb, C, ldc, bias);
+    if (!a_t && split && !bias && wsx3_applicable(M, N, K) && (b_t ? ldb % 4 == 0 : true)) return gemm_wsx3(stream, b_t, M, N, K, A, lda, B, ldb, C, ldc, accumulate);
     const int splits = gemm_splits(M, N, K, a_t);
     int tm = 2, tn = 2;
     if (splits == 1) gemm_tile(M, N, K, &tm, &tn);

@@ -144,3 +144,26 @@ def test_gemm_weight_stationary(dev, b_t, M, N, K):
         call("gsat_gemm_f32", 0, int(b_t), M, N, K, ptr(A), K, ptr(B), B.shape[1], ptr(C), N, None, 0, None, 0, stream())
         outs.append(C)
     assert torch.equal(outs[0], outs[1])
+
+
+@pytest.mark.parametrize("b_t", [True, False])
+@pytest.mark.parametrize("M,N,K", [
+    (51639, 256, 128), (51639, 128, 256),      # C3 extractor backward: da1 = dh2 W2 (8 column blocks) ; demb = dh1 W1 (4 column blocks x 2 k-splits)
+    (12801, 256, 64), (12801, 64, 256),        # H = 64 edge mode
+    (9001, 128, 64), (9001, 64, 128),
+    (20000, 256, 512), (8193, 32, 256),        # 8 fragment steps of 16 k at K = 512 ; one column block, 8 k-splits
+])
+def test_gemm_weight_stationary_split_bf16(dev, bf16x3, b_t, M, N, K):
+    """The persistent weight-stationary kernel on the split-bf16 path (backward-data products of the extractor, M >= 8192): every wave
+    geometry, ragged last tile, accumulate, bitwise determinism; error inside the split-bf16 band (~1e-5 of the output scale)."""
+    rel = _run_split(dev, False, b_t, M, N, K)
+    assert rel < 5e-5
+    _run_split(dev, False, b_t, M, N, K, accumulate=True)
+    from dp_gsat_amd._lib import call, ptr, stream
+    A = torch.randn(M, K, device=dev); B = torch.randn((N, K) if b_t else (K, N), device=dev)
+    outs = []
+    for _ in range(2):
+        C = torch.empty(M, N, device=dev)
+        call("gsat_gemm_bf16x3", 0, int(b_t), M, N, K, ptr(A), K, ptr(B), B.shape[1], ptr(C), N, None, 0, None, 0, stream())
+        outs.append(C)
+    assert torch.equal(outs[0], outs[1])
