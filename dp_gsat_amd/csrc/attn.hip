@@ -33,10 +33,10 @@ struct GemmWs { float* ptr; size_t floats; };
 // 1e-5 of each gradient's own scale.  The forward products feed an InstanceNorm directly: 1/sigma of a nearly constant channel
 // turns the same perturbation of h into ~3e2 x 1e-5 of the normalised value, so they stay exact fp32.
 static int gemm_rm(hipStream_t stream, bool ta, bool tb, int64_t M, int64_t N, int64_t K, const float* A, int64_t lda, const float* B,
-                   int64_t ldb, float beta, float* C, int64_t ldc, GemmWs ws = {nullptr, 0}, bool split_ok = false) {
+                   int64_t ldb, float beta, float* C, int64_t ldc, GemmWs ws = {nullptr, 0}, bool split_ok = false, SlabJob* defer = nullptr) {
     const char* env = getenv("GSAT_ATTN_BWD_SPLIT");                    // read per call: bench.py times both settings in one process
     const bool bwd_split = !(env && atoi(env) == 0);
-    return gemm_f32(stream, ta, tb, M, N, K, A, lda, B, ldb, C, ldc, nullptr, beta != 0.f, ws.ptr, ws.floats, split_ok && bwd_split);
+    return gemm_f32(stream, ta, tb, M, N, K, A, lda, B, ldb, C, ldc, nullptr, beta != 0.f, ws.ptr, ws.floats, split_ok && bwd_split, defer);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -719,11 +719,11 @@ static int launch_seg_stats(hipStream_t stream, PreAct<EDGE> pre, const int32_t*
     return GSAT_OK;
 }
 
-static size_t attn_gemm_ws_floats(const gsat_attn_args* a) {
-    const size_t w2 = gemm_workspace_floats(a->C2, a->C1, a->M, true);
-    const size_t w1 = gemm_workspace_floats(a->C1, a->H, a->N, true);
-    return w1 > w2 ? w1 : w2;
-}
+// split-K slabs of the weight-gradient GEMMs: dW2, dW1 (edge mode: its two halves).  Each keeps its own region, because their ordered
+// sums are deferred to ONE launch at the end of the backward (slab_reduce_jobs)
+static size_t attn_gemm_ws_w2(const gsat_attn_args* a) { return align_up(gemm_workspace_floats(a->C2, a->C1, a->M, true), 64); }
+static size_t attn_gemm_ws_w1(const gsat_attn_args* a) { return align_up(gemm_workspace_floats(a->C1, a->H, a->N, true), 64); }
+static size_t attn_gemm_ws_floats(const gsat_attn_args* a) { return attn_gemm_ws_w2(a) + (a->edge_mode ? 2 : 1) * attn_gemm_ws_w1(a); }
 
 static int check_args(const gsat_attn_args* a, const char* who) {
     GSAT_REQUIRE(a, GSAT_ERR_ARG, "%s: null args", who);
@@ -900,8 +900,11 @@ int gsat_attn_bwd(const gsat_attn_args* a, const gsat_attn_grads* gr, void* stre
         dQ = ar.take<float>((size_t)N * C1);
         lpart = ar.take<float>(gsat_long_row_partial_floats(M, C1));
     }
-    GemmWs gws{nullptr, attn_gemm_ws_floats(a)};
+    GemmWs gws{nullptr, attn_gemm_ws_w2(a)}, gws1{nullptr, attn_gemm_ws_w1(a)}, gws1b{nullptr, a->edge_mode ? attn_gemm_ws_w1(a) : 0};
     gws.ptr = ar.take<float>(gws.floats);
+    gws1.ptr = ar.take<float>(gws1.floats);
+    gws1b.ptr = ar.take<float>(gws1b.floats);
+    SlabJob jobs[3] = {};                        // pending ordered sums of dW2, dW1 (| its two halves): one launch at the end
     const size_t dws_bytes = std::max(dual_gemm_ws_bytes(1, C2, C1, C1), dual_gemm_ws_bytes(2, C1, H, H));
     char* dws = ar.take<char>(dws_bytes);
     const bool fused_bwd = attn_fused_bwd_eligible(a) && seg_slices(M, G) == 1;
@@ -957,7 +960,7 @@ int gsat_attn_bwd(const gsat_attn_args* a, const gsat_attn_grads* gr, void* stre
     if (dual_gemm_ok(1, M, C2, C1, C1)) {            // both products in one pass over dh2 (dual_gemm.hip)
         if ((rc = dual_gemm(stream, 1, M, C2, C1, C1, dh2, C2, a->a1, C1, a->W2, C1, da1, C1, 0, gr->dW2, C1, dws, dws_bytes))) return rc;
     } else {
-        if ((rc = gemm_rm(stream, true, false, C2, C1, M, dh2, C2, a->a1, C1, 0.f, gr->dW2, C1, gws, true))) return rc;
+        if ((rc = gemm_rm(stream, true, false, C2, C1, M, dh2, C2, a->a1, C1, 0.f, gr->dW2, C1, gws, true, &jobs[0]))) return rc;
         if ((rc = gemm_rm(stream, false, false, M, C1, C2, dh2, C2, a->W2, C1, 0.f, da1, C1, GemmWs{nullptr, 0}, true))) return rc;
     }
     // ---- through ReLU/dropout and the first InstanceNorm ---------------------------------------
@@ -997,8 +1000,8 @@ int gsat_attn_bwd(const gsat_attn_args* a, const gsat_attn_grads* gr, void* stre
         } else {
         if ((rc = gemm_rm(stream, false, false, N, H, C1, dP, C1, a->W1, 2 * H, 0.f, gr->demb, H, GemmWs{nullptr, 0}, true))) return rc;
         if ((rc = gemm_rm(stream, false, false, N, H, C1, dQ, C1, a->W1 + H, 2 * H, 1.f, gr->demb, H, GemmWs{nullptr, 0}, true))) return rc;
-        if ((rc = gemm_rm(stream, true, false, C1, H, N, dP, C1, a->emb, H, 0.f, gr->dW1, 2 * H, gws, true))) return rc;
-        if ((rc = gemm_rm(stream, true, false, C1, H, N, dQ, C1, a->emb, H, 0.f, gr->dW1 + H, 2 * H, gws, true))) return rc;
+        if ((rc = gemm_rm(stream, true, false, C1, H, N, dP, C1, a->emb, H, 0.f, gr->dW1, 2 * H, gws1, true, &jobs[1]))) return rc;
+        if ((rc = gemm_rm(stream, true, false, C1, H, N, dQ, C1, a->emb, H, 0.f, gr->dW1 + H, 2 * H, gws1b, true, &jobs[2]))) return rc;
         }
     } else {
         if (Z > 1) {
@@ -1010,10 +1013,10 @@ int gsat_attn_bwd(const gsat_attn_args* a, const gsat_attn_grads* gr, void* stre
             if ((rc = dual_gemm(stream, 2, N, C1, H, H, da1, C1, a->emb, H, a->W1, H, gr->demb, H, 0, gr->dW1, H, dws, dws_bytes))) return rc;
         } else {
         if ((rc = gemm_rm(stream, false, false, N, H, C1, da1, C1, a->W1, H, 0.f, gr->demb, H, GemmWs{nullptr, 0}, true))) return rc;
-        if ((rc = gemm_rm(stream, true, false, C1, H, N, da1, C1, a->emb, H, 0.f, gr->dW1, H, gws, true))) return rc;
+        if ((rc = gemm_rm(stream, true, false, C1, H, N, da1, C1, a->emb, H, 0.f, gr->dW1, H, gws1, true, &jobs[1]))) return rc;
         }
     }
-    return GSAT_OK;
+    return slab_reduce_jobs(stream, jobs, 3);
 }
 
 int gsat_instance_norm_fwd(const float* x, const int32_t* seg_ptr, const int32_t* seg_order, const int32_t* row_seg, int64_t M,

@@ -57,8 +57,13 @@ struct Arena {
 };
 
 // ---- fp32 MFMA GEMM (gemm.hip): C[M,N] (+)= op(A) op(B) (+ bias) --------------------------------
+// `defer` != NULL: a split-K product leaves the ordered sum of its partial slabs to the caller (slab_reduce_jobs: several products' sums
+// in ONE launch); defer->nslab == 0 afterwards means nothing is pending (no split, or the sum was done here)
+struct SlabJob { const float* ws; int nslab; size_t slab; int M, N; int64_t ldc; int accumulate; float* out; };
 int gemm_f32(hipStream_t stream, bool a_t, bool b_t, int64_t M, int64_t N, int64_t K, const float* A, int64_t lda, const float* B,
-             int64_t ldb, float* C, int64_t ldc, const float* bias, bool accumulate, float* ws, size_t ws_floats, bool allow_split = false);
+             int64_t ldb, float* C, int64_t ldc, const float* bias, bool accumulate, float* ws, size_t ws_floats, bool allow_split = false,
+             SlabJob* defer = nullptr);
+int slab_reduce_jobs(hipStream_t stream, const SlabJob* jobs, int n);
 size_t gemm_workspace_floats(int64_t M, int64_t N, int64_t K, bool reduce_rows);
 
 // ---- gather-sum over a CSR (aggregate.hip), reused by the extractor backward -------------------------

@@ -723,9 +723,23 @@ __global__ void k_slab_reduce(const float* __restrict__ slabs, int nslab, size_t
 // The same sum with four lanes per float4 of the output: lane q of a quad adds slabs q, q+4, q+8, ... (two independent partial sums, so
 // the loads pipeline), then the quad combines in a fixed tree.  4x the loads in flight and 16-byte accesses: 10.8 -> ~4 us for the
 // 128 x 32768 slabs of the extractor's weight gradients at C3.  Bitwise reproducible (the order never depends on timing).
+__device__ __forceinline__ void slab_reduce4_body(int64_t t, const float* __restrict__ slabs, int nslab, size_t slab_stride, int M, int N, int64_t ldc,
+                                                  int accumulate, float* __restrict__ out);
 __global__ void k_slab_reduce4(const float* __restrict__ slabs, int nslab, size_t slab_stride, int M, int N, int64_t ldc,
                                int accumulate, float* __restrict__ out) {
-    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    slab_reduce4_body((int64_t)blockIdx.x * blockDim.x + threadIdx.x, slabs, nslab, slab_stride, M, N, ldc, accumulate, out);
+}
+// up to four pending sums in one launch: job j owns blocks [first[j], first[j + 1])
+struct SlabJobs4 { SlabJob job[4]; int first[5]; };
+__global__ void k_slab_reduce_jobs(const SlabJobs4 J) {
+    int j = 0;
+#pragma unroll
+    for (int q = 1; q < 4; ++q) j += (int)blockIdx.x >= J.first[q] ? 1 : 0;
+    const SlabJob& b = J.job[j];
+    slab_reduce4_body((int64_t)(blockIdx.x - J.first[j]) * blockDim.x + threadIdx.x, b.ws, b.nslab, b.slab, b.M, b.N, b.ldc, b.accumulate, b.out);
+}
+__device__ __forceinline__ void slab_reduce4_body(int64_t t, const float* __restrict__ slabs, int nslab, size_t slab_stride, int M, int N, int64_t ldc,
+                                                  int accumulate, float* __restrict__ out) {
     const int q = (int)(t & 3);
     const int64_t i4 = t >> 2;                                    // float4 index into the [M, N] output
     const bool live = i4 < (int64_t)M * N / 4;
@@ -912,7 +926,8 @@ static int gemm_wsx3(hipStream_t stream, bool b_t, int64_t M, int64_t N, int64_t
 // C[M,N] (+)= op(A) op(B) (+ bias).  a_t: A given as [K,M]; b_t: B given as [N,K].  K % 4 == 0 and the
 // contiguous extents must be multiples of 4 (float4 staging).  `ws` is needed when gemm_splits() > 1.
 int gemm_f32(hipStream_t stream, bool a_t, bool b_t, int64_t M, int64_t N, int64_t K, const float* A, int64_t lda, const float* B,
-             int64_t ldb, float* C, int64_t ldc, const float* bias, bool accumulate, float* ws, size_t ws_floats, bool allow_split) {
+             int64_t ldb, float* C, int64_t ldc, const float* bias, bool accumulate, float* ws, size_t ws_floats, bool allow_split, SlabJob* defer) {
+    if (defer) defer->nslab = 0;
     if (M <= 0 || N <= 0) return GSAT_OK;
     xcd_switch_once();
     GSAT_REQUIRE(K > 0 && A && B && C, GSAT_ERR_ARG, "gemm_f32: bad argument");
@@ -961,12 +976,32 @@ int gemm_f32(hipStream_t stream, bool a_t, bool b_t, int64_t M, int64_t N, int64
 #undef LAUNCH
     GSAT_LAUNCH_CHECK();
     if (splits > 1) {
-        if (N % 4 == 0 && ldc % 4 == 0 && slab % 4 == 0 && ((uintptr_t)C & 15) == 0 && ((uintptr_t)ws & 15) == 0)
+        const bool vec = N % 4 == 0 && ldc % 4 == 0 && slab % 4 == 0 && ((uintptr_t)C & 15) == 0 && ((uintptr_t)ws & 15) == 0;
+        if (defer && vec) { *defer = SlabJob{ws, splits, slab, (int)M, (int)N, ldc, accumulate ? 1 : 0, C}; return GSAT_OK; }
+        if (vec)
             k_slab_reduce4<<<(unsigned)ceil_div(M * N, 256), 256, 0, stream>>>(ws, splits, slab, (int)M, (int)N, ldc, accumulate ? 1 : 0, C);
         else
             k_slab_reduce<<<(unsigned)ceil_div(M * N, 256), 256, 0, stream>>>(ws, splits, slab, (int)M, (int)N, ldc, accumulate ? 1 : 0, C);
         GSAT_LAUNCH_CHECK();
     }
+    return GSAT_OK;
+}
+
+int slab_reduce_jobs(hipStream_t stream, const SlabJob* jobs, int n) {
+    SlabJobs4 J{};
+    int m = 0, blocks = 0;
+    for (int i = 0; i < n; ++i) {
+        if (jobs[i].nslab <= 0) continue;
+        GSAT_REQUIRE(m < 4, GSAT_ERR_ARG, "slab_reduce_jobs: more than four pending sums");
+        J.job[m] = jobs[i];
+        J.first[m] = blocks;
+        blocks += (int)ceil_div((int64_t)jobs[i].M * jobs[i].N, 256);
+        ++m;
+    }
+    for (int q = m; q <= 4; ++q) J.first[q] = blocks;
+    if (!blocks) return GSAT_OK;
+    k_slab_reduce_jobs<<<blocks, 256, 0, stream>>>(J);
+    GSAT_LAUNCH_CHECK();
     return GSAT_OK;
 }
 
