@@ -691,7 +691,10 @@ __global__ __launch_bounds__(WS_THREADS, 2) void k_gemm_ws_x3(const float* __res
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
                     const int rr = (r & 3) + 8 * (r >> 2);
-                    if (m0 + 4 * h + rr < M) crow[(size_t)rr * ldc] = accumulate ? crow[(size_t)rr * ldc] + acc[r] : acc[r];
+                    if (m0 + 4 * h + rr < M) {
+                        if (accumulate & 2) __builtin_nontemporal_store(acc[r], crow + (size_t)rr * ldc);
+                        else crow[(size_t)rr * ldc] = (accumulate & 1) ? crow[(size_t)rr * ldc] + acc[r] : acc[r];
+                    }
                 }
             }
         }
@@ -876,8 +879,10 @@ static int gemm_ws(hipStream_t stream, bool b_t, int64_t M, int64_t N, int64_t K
 
 // ---- weight-stationary split-bf16 dispatch ------------------------------------------------------------------------
 static bool wsx3_geometry(int64_t N, int64_t K, int* nb, int* ksteps) {
-    if (N % 32 != 0 || N > 256 || (K != 64 && K != 128 && K != 256 && K != 512)) return false;
-    const int64_t NB = N / 32;
+    // wider outputs run as 256-column chunks (gridDim.y): every chunk streams all rows of A (the re-reads stay in the Infinity Cache for the
+    // backbone's dx = dy W: 51 639 x 1024 x 128 at C3, 85 us on the tile kernel for a 211 MB output, 62 us here)
+    if (N % 32 != 0 || (N > 256 && N % 256 != 0) || (K != 64 && K != 128 && K != 256 && K != 512)) return false;
+    const int64_t NB = (N > 256 ? 256 : N) / 32;
     if (NB != 1 && NB != 2 && NB != 4 && NB != 8) return false;
     const int64_t KS = 8 / NB, Kw = K / KS;
     if (Kw % 16 != 0) return false;
@@ -912,8 +917,12 @@ static int gemm_wsx3(hipStream_t stream, bool b_t, int64_t M, int64_t N, int64_t
     const size_t lds = (size_t)4 * WS_ROWS * (2 * K + 16);
     const int nq = (int)(K / 64);
     const int per_cu = (2 * lds <= 150 * 1024 && st * 8 + nq * 9 <= 84) ? 2 : 1;      // two workgroups per CU need <= 128 registers (fragments + staging)
-    const dim3 grid((unsigned)std::min<int64_t>(tiles, (int64_t)256 * per_cu), 1);
-#define XGO(BT, S, Q) return wsx3_launch<BT, S, Q>(stream, grid, lds, A, lda, B, ldb, C, ldc, (int)M, (int)N, (int)K, nb, accumulate ? 1 : 0, tiles)
+    const int chunks = (int)ceil_div(N, 256);
+    const dim3 grid((unsigned)std::min<int64_t>(tiles, std::max<int64_t>(1, (int64_t)256 * per_cu / chunks)), (unsigned)chunks);
+    // bit 1: streaming output (too large for the caches to keep until its consumer runs)
+    static const int nt_mode = getenv("GSAT_GEMM_NT") ? atoi(getenv("GSAT_GEMM_NT")) : 1;
+    const int acc_flag = (accumulate ? 1 : 0) | ((nt_mode && !accumulate && (size_t)M * N * 4 >= ((size_t)64 << 20)) ? 2 : 0);
+#define XGO(BT, S, Q) return wsx3_launch<BT, S, Q>(stream, grid, lds, A, lda, B, ldb, C, ldc, (int)M, (int)N, (int)K, nb, acc_flag, tiles)
 #define XQ(BT, S) do { switch (nq) { case 1: XGO(BT, S, 1); case 2: XGO(BT, S, 2); case 4: XGO(BT, S, 4); case 8: XGO(BT, S, 8); default: break; } } while (0)
 #define XS(BT) do { switch (st) { case 2: XQ(BT, 2); break; case 4: XQ(BT, 4); break; default: XQ(BT, 8); break; } } while (0)
     if (b_t) XS(true); else XS(false);

@@ -152,6 +152,7 @@ def test_gemm_weight_stationary(dev, b_t, M, N, K):
     (12801, 256, 64), (12801, 64, 256),        # H = 64 edge mode
     (9001, 128, 64), (9001, 64, 128),
     (20000, 256, 512), (8193, 32, 256),        # 8 fragment steps of 16 k at K = 512 ; one column block, 8 k-splits
+    (20001, 1024, 128), (9000, 512, 64),       # wide outputs: 256-column chunks (the backbone's dx = dy W at C3: 51 639 x 1024 x 128)
 ])
 def test_gemm_weight_stationary_split_bf16(dev, bf16x3, b_t, M, N, K):
     """The persistent weight-stationary kernel on the split-bf16 path (backward-data products of the extractor, M >= 8192): every wave
