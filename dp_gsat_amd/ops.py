@@ -891,7 +891,7 @@ class PnaConvFn(torch.autograd.Function):
 def pna_conv(x, index, att, edge_emb, aggregators, scalers, avg_deg, weight, bias):
     """post_nn[0](pna_aggregate(...)) for a PNAConvSimple whose post_nn is one Linear, on the compact aggregate -- opt-in
     (GSAT_PNA_COMPACT=1): measured on MI355X at C3 (profiles/r03_summary.md) the aggregation forward drops from 45 to 24 us per layer
-    pass, but the post_nn GEMMs, whose split-bf16 staging is already vector-ALU bound, pay more for rebuilding the x_i columns (forward 57
+    pass, but the post_nn GEMMs, whose split-bf16 staging is already vector-ALU bound, pay more for rebuilding the x_i columns (forward 65-70
     -> 87 us, weight gradient 79 -> 96 us) than the halved traffic returns: whole step 4.69 vs 4.55 ms.  Returns None when not taken (the
     caller runs the two ops)."""
     a = [AGGREGATOR_CODES[k] for k in aggregators]
