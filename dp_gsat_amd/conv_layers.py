@@ -73,17 +73,24 @@ class PNAConvSimple(nn.Module):
             modules += [nn.ReLU(), Linear(self.F_out, self.F_out)]
         self.post_nn = nn.Sequential(*modules)
 
-    def forward(self, x, edge_index, edge_attr=None, edge_atten=None, index=None):
+    def forward(self, x, edge_index, edge_attr=None, edge_atten=None, index=None, with_residual_input: bool = False):
+        """``with_residual_input``: return ``(out, x_id)`` where ``x_id`` is ``x`` as an identity output of the aggregation's autograd node: a
+        layer that also adds ``x`` as its residual (src/models/pna.py:57-59) uses ``x_id`` there, and that path's gradient is then added
+        inside the aggregation backward instead of by a separate [N,H] add per layer."""
         index = _index_of(edge_index, x, index)
+        x_id = x
         if len(self.post_nn) == 1:           # one Linear behind the aggregation: one autograd node on the compact aggregate when possible
             lin = self.post_nn[0]
-            out = pna_conv(x, index, edge_atten, edge_attr, self.aggregators, self.scalers, self.avg_deg, lin.weight, lin.bias)
+            out = pna_conv(x, index, edge_atten, edge_attr, self.aggregators, self.scalers, self.avg_deg, lin.weight, lin.bias, with_residual_input)
             if out is not None:
                 return out
-        agg = pna_aggregate(x, index, edge_atten, edge_attr, self.aggregators, self.scalers, self.avg_deg)
+        agg = pna_aggregate(x, index, edge_atten, edge_attr, self.aggregators, self.scalers, self.avg_deg, with_residual_input and x.is_cuda)
+        if isinstance(agg, tuple):
+            agg, x_id = agg
         if agg.shape[1] != self.post_nn[0].in_features:
             raise ValueError(f"PNAConvSimple was built for F_in={self.F_in} but the message is {agg.shape[1]} wide")
-        return self.post_nn(agg)
+        out = self.post_nn(agg)
+        return (out, x_id) if with_residual_input else out
 
     def __repr__(self):
         return f"{self.__class__.__name__}({self.in_channels}, {self.out_channels})"

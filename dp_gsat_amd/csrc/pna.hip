@@ -686,7 +686,7 @@ __global__ __launch_bounds__(TILE_BLOCK, 4) void k_pna_bwd_tile(
     const float* __restrict__ x, const float* __restrict__ att, const float* __restrict__ dout, const int32_t* __restrict__ rowptr,
     const int32_t* __restrict__ col, const int32_t* __restrict__ eid, const int4* __restrict__ desc,
     const int32_t* __restrict__ rowptr_src, const int32_t* __restrict__ slot_map, int H, int TE, int RCAP, float* dx,
-    float* __restrict__ dmsg, float* datt, float* __restrict__ dw) {
+    float* __restrict__ dmsg, float* datt, float* __restrict__ dw, const float* __restrict__ dx_add) {
     constexpr int GPB = LaneGroups<LPR, TILE_BLOCK>::GPB;     // lane groups (rows in flight) per workgroup
     constexpr int RPW = 64 / LPR;                // rows covered by one wave-instruction
     constexpr int NSEG = NAGG * 2;
@@ -884,6 +884,10 @@ __global__ __launch_bounds__(TILE_BLOCK, 4) void k_pna_bwd_tile(
         if (!on) continue;
         const int sb = s_rps[j - n0], se = s_rps[j - n0 + 1];
         float4 acc = ld4(dx + (size_t)j * H + c);
+        if (dx_add) {              // a gradient that reaches x by another path (the layer's residual): added here instead of by a separate kernel
+            const float4 r = ld4(dx_add + (size_t)j * H + c);
+            acc.x += r.x; acc.y += r.y; acc.z += r.z; acc.w += r.w;
+        }
         float sw = 0.f;
         for (int s_ = sb; s_ < se; ++s_) {
             const int kl = s_ < nsl ? s_slot[s_] : slot_map[s0 + s_] - k0;
@@ -1207,7 +1211,7 @@ static int pna_bwd_tiled_impl(const char* who, bool natt, const float* x, const 
                               int rows_cap, int edges_cap, const int32_t* rowptr_src, const int32_t* slot_dst_of_srcslot, int64_t N,
                               int64_t E, int64_t H, const int32_t* aggregators, int A, const int32_t* scalers, int S,
                               const int32_t* spill_rows, const int32_t* spill_count, float* dx, float* dmsg, float* datt, float* dw,
-                              hipStream_t stream) {
+                              const float* dx_add, hipStream_t stream) {
     GSAT_REQUIRE(N >= 0 && N < (1ll << 31) && E >= 0 && num_tiles >= 0, GSAT_ERR_ARG, "%s: bad extents", who);
     PnaCfg cfg;
     int rc = make_cfg(aggregators, A, scalers, S, 1.f, 1.f, &cfg);
@@ -1226,7 +1230,7 @@ static int pna_bwd_tiled_impl(const char* who, bool natt, const float* x, const 
     do {                                                                                                                     \
         GSAT_CHECK_HIP((pna_tile_allow_lds<L, NA, NT>(lds)));                                                                \
         k_pna_bwd_tile<L, NA, NT><<<(int)num_tiles, TILE_BLOCK, lds, stream>>>(x, att, dout, rowptr, col, eid, (const int4*)tile_desc,     \
-                                                                          rowptr_src, slot_dst_of_srcslot, (int)H, edges_cap, rows_cap, dx, dmsg, datt, dw); \
+                                                                          rowptr_src, slot_dst_of_srcslot, (int)H, edges_cap, rows_cap, dx, dmsg, datt, dw, dx_add); \
     } while (0)
 #define CALL(L) do { if (natt) { if (nagg == 4) GO(L, 4, true); else GO(L, 5, true); } else { if (nagg == 4) GO(L, 4, false); else GO(L, 5, false); } } while (0)
     if (num_tiles > 0) { GSAT_LPR_DISPATCH(lpr, CALL); }
@@ -1250,20 +1254,21 @@ int gsat_pna_bwd_tiled(const float* x, const float* att, const float* dout, cons
                        const int32_t* eid, const int32_t* tile_desc, int64_t num_tiles, int rows_nominal, int rows_cap, int edges_cap,
                        const int32_t* rowptr_src, const int32_t* slot_dst_of_srcslot, int64_t N, int64_t E, int64_t H,
                        const int32_t* aggregators, int A, const int32_t* scalers, int S, const int32_t* spill_rows,
-                       const int32_t* spill_count, float* dx, float* dmsg, float* datt, void* stream_) {
+                       const int32_t* spill_count, float* dx, float* dmsg, float* datt, const float* dx_add, void* stream_) {
     return pna_bwd_tiled_impl("gsat_pna_bwd_tiled", false, x, att, dout, rowptr, col, eid, tile_desc, num_tiles, rows_nominal, rows_cap, edges_cap,
                               rowptr_src, slot_dst_of_srcslot, N, E, H, aggregators, A, scalers, S, spill_rows, spill_count, dx, dmsg, datt,
-                              nullptr, (hipStream_t)stream_);
+                              nullptr, dx_add, (hipStream_t)stream_);
 }
 
 int gsat_pna_bwd_tiled_node_att(const float* x, const float* node_att, const float* dout, const int32_t* rowptr, const int32_t* col,
                                 const int32_t* tile_desc, int64_t num_tiles, int rows_nominal, int rows_cap, int edges_cap,
                                 const int32_t* rowptr_src, const int32_t* slot_dst_of_srcslot, int64_t N, int64_t E, int64_t H,
                                 const int32_t* aggregators, int A, const int32_t* scalers, int S, const int32_t* spill_rows,
-                                const int32_t* spill_count, float* dx, float* dmsg, float* dnode_att, float* dw, void* stream_) {
+                                const int32_t* spill_count, float* dx, float* dmsg, float* dnode_att, float* dw, const float* dx_add,
+                                void* stream_) {
     return pna_bwd_tiled_impl("gsat_pna_bwd_tiled_node_att", true, x, node_att, dout, rowptr, col, nullptr, tile_desc, num_tiles, rows_nominal,
                               rows_cap, edges_cap, rowptr_src, slot_dst_of_srcslot, N, E, H, aggregators, A, scalers, S, spill_rows, spill_count,
-                              dx, dmsg, dnode_att, dw, (hipStream_t)stream_);
+                              dx, dmsg, dnode_att, dw, dx_add, (hipStream_t)stream_);
 }
 
 }  // extern "C"

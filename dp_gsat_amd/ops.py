@@ -179,11 +179,18 @@ class PnaAggregate(torch.autograd.Function):
     replaces: PNAConvSimple.message/aggregate (src/models/conv_layers.py:166-185, 193-259)."""
 
     @staticmethod
-    def forward(ctx, x, att, edge_emb, index: BatchIndex, aggr_codes, scaler_codes, avg_lin: float, avg_log: float, node_att=None):
+    def forward(ctx, x, att, edge_emb, index: BatchIndex, aggr_codes, scaler_codes, avg_lin: float, avg_log: float, node_att=None,
+                passthrough: bool = False):
+        # passthrough: ALSO return x itself (an identity output of this node).  A caller that feeds it to a second consumer of x -- the
+        # layer's residual, src/models/pna.py:57-59 -- has that path's gradient arrive HERE, where the tiled backward adds it inside its
+        # own dx pass (dx_add) instead of autograd launching one [N,H] add per layer.
         import ctypes
+        x_in = x
         x = _f32c(x)
+        ctx.passthrough = bool(passthrough)
         if node_att is not None:
-            return PnaAggregate._forward_node_att(ctx, x, node_att, index, aggr_codes, scaler_codes, avg_lin, avg_log)
+            out = PnaAggregate._forward_node_att(ctx, x, node_att, index, aggr_codes, scaler_codes, avg_lin, avg_log)
+            return (out, x_in) if passthrough else out
         ctx.node_att = False
         attf = _flat_att(att, index.E)
         edge_emb = _f32c(edge_emb)
@@ -209,7 +216,7 @@ class PnaAggregate(torch.autograd.Function):
         ctx.index = index
         ctx.cfg = (tuple(aggr_codes), tuple(scaler_codes), float(avg_lin), float(avg_log))
         ctx.att_shape = None if att is None else att.shape
-        return out
+        return (out, x_in) if passthrough else out
 
     @staticmethod
     def _forward_node_att(ctx, x, node_att, index, aggr_codes, scaler_codes, avg_lin, avg_log):
@@ -233,7 +240,7 @@ class PnaAggregate(torch.autograd.Function):
         return out
 
     @staticmethod
-    def _backward_node_att(ctx, dout):
+    def _backward_node_att(ctx, dout, dx_add=None):
         import ctypes
         x, na = ctx.saved_tensors
         index = ctx.index
@@ -252,14 +259,17 @@ class PnaAggregate(torch.autograd.Function):
         dx = torch.empty_like(x)
         call("gsat_pna_bwd_tiled_node_att", ptr(x), ptr(na), ptr(dout), ptr(index.rowptr_dst), ptr(index.src_by_dst), ptr(tile_ptr), T,
              rows_nominal, rows_cap, edges_cap, ptr(index.rowptr_src), ptr(index.slot_dst_of_srcslot), N, index.E, H, a_arr, A, s_arr, S,
-             ptr(spill[1:]), ptr(spill[:1]), ptr(dx), ptr(dmsg), ptr(dna), ptr(dw), stream())
-        return dx, None, None, None, None, None, None, None, (dna.view(ctx.att_shape) if need_att else None)
+             ptr(spill[1:]), ptr(spill[:1]), ptr(dx), ptr(dmsg), ptr(dna), ptr(dw), ptr(dx_add), stream())
+        return dx, None, None, None, None, None, None, None, (dna.view(ctx.att_shape) if need_att else None), None
 
     @staticmethod
-    def backward(ctx, dout):
+    def backward(ctx, dout, dx_add=None):
         import ctypes
+        dx_add = None if dx_add is None else _f32c(dx_add)
+        if dout is None:                       # only the identity output was used
+            return dx_add, None, None, None, None, None, None, None, None, None
         if ctx.node_att:
-            return PnaAggregate._backward_node_att(ctx, dout)
+            return PnaAggregate._backward_node_att(ctx, dout, dx_add)
         x, attf, edge_emb = ctx.saved_tensors
         index = ctx.index
         aggr_codes, scaler_codes, avg_lin, avg_log = ctx.cfg
@@ -287,8 +297,8 @@ class PnaAggregate(torch.autograd.Function):
             dx = torch.empty_like(x)
             call("gsat_pna_bwd_tiled", ptr(x), ptr(attf), ptr(dout), ptr(index.rowptr_dst), ptr(index.src_by_dst), ptr(index.eid_by_dst),
                  ptr(tile_ptr), T, rows_nominal, rows_cap, edges_cap, ptr(index.rowptr_src), ptr(index.slot_dst_of_srcslot), N, index.E, H,
-                 a_arr, A, s_arr, S, ptr(spill[1:]), ptr(spill[:1]), ptr(dx), ptr(dmsg), ptr(datt), stream())
-            return dx, (datt.view(ctx.att_shape) if need_att else None), None, None, None, None, None, None, None
+                 a_arr, A, s_arr, S, ptr(spill[1:]), ptr(spill[:1]), ptr(dx), ptr(dmsg), ptr(datt), ptr(dx_add), stream())
+            return dx, (datt.view(ctx.att_shape) if need_att else None), None, None, None, None, None, None, None, None
         dx_self = torch.empty_like(x)
         dee = torch.empty_like(edge_emb) if need_ee else None
         if hubs is not None:
@@ -304,10 +314,12 @@ class PnaAggregate(torch.autograd.Function):
         call("gsat_aggr_sum_fwd", ptr(dmsg), ptr(dx_self), None, None, ptr(index.rowptr_src),
              ptr(index.slot_dst_of_srcslot), None, N, index.E, H, 1.0, ptr(dx),
              ptr(index.long_rows[1]), ptr(index.partial(H)) if index.long_rows[1] is not None else None, stream())
-        return dx, (datt.view(ctx.att_shape) if need_att else None), dee, None, None, None, None, None, None
+        if dx_add is not None:
+            dx = dx + dx_add
+        return dx, (datt.view(ctx.att_shape) if need_att else None), dee, None, None, None, None, None, None, None
 
 
-def pna_aggregate(x, index, att, edge_emb, aggregators, scalers, avg_deg):
+def pna_aggregate(x, index, att, edge_emb, aggregators, scalers, avg_deg, passthrough: bool = False):
     a = [AGGREGATOR_CODES[k] for k in aggregators]
     s = [SCALER_CODES[k] for k in scalers]
     if isinstance(att, LiftedAttention):
@@ -316,9 +328,9 @@ def pna_aggregate(x, index, att, edge_emb, aggregators, scalers, avg_deg):
         if (edge_emb is None and att.index is index and _FIXED_PNA.get((tuple(a), tuple(s))) and index.long_rows_nowait[0] is None
                 and os.environ.get("GSAT_PNA_TILED", "1") != "0" and os.environ.get("GSAT_NODE_ATT_LIFT", "0") != "1"
                 and att._edge is None and index.pna_tiles(x.shape[1])):
-            return PnaAggregate.apply(x, None, None, index, a, s, avg_deg["lin"], avg_deg["log"], att.node_att)
+            return PnaAggregate.apply(x, None, None, index, a, s, avg_deg["lin"], avg_deg["log"], att.node_att, passthrough)
         att = att.edge()
-    return PnaAggregate.apply(x, att, edge_emb, index, a, s, avg_deg["lin"], avg_deg["log"])
+    return PnaAggregate.apply(x, att, edge_emb, index, a, s, avg_deg["lin"], avg_deg["log"], None, passthrough)
 
 
 # ------------------------------------------------------------------------------------------------
@@ -808,8 +820,10 @@ class PnaConvFn(torch.autograd.Function):
     saved activation.  Edge weights: none, an [E] tensor, or node attention formed inside the kernels."""
 
     @staticmethod
-    def forward(ctx, x, att, node_att, weight, bias, index: BatchIndex, aggr_codes):
+    def forward(ctx, x, att, node_att, weight, bias, index: BatchIndex, aggr_codes, passthrough: bool = False):
         import ctypes
+        x_in = x
+        ctx.passthrough = bool(passthrough)
         x, weight = _f32c(x), _f32c(weight)
         bias = None if bias is None else _f32c(bias)
         N, H = x.shape
@@ -838,12 +852,15 @@ class PnaConvFn(torch.autograd.Function):
         ctx.mode = "node" if node_att is not None else ("edge" if att is not None else "none")
         ctx.att_shape = node_att.shape if node_att is not None else (att.shape if att is not None else None)
         ctx.has_bias = bias is not None
-        return out
+        return (out, x_in) if passthrough else out
 
     @staticmethod
-    def backward(ctx, dout):
+    def backward(ctx, dout, dx_add=None):
         import ctypes
         from ._lib import load
+        dx_add = None if dx_add is None else _f32c(dx_add)
+        if dout is None:
+            return dx_add, None, None, None, None, None, None, None
         x, w, aggj, scal, weight = ctx.saved_tensors
         index, aggr_codes = ctx.index, ctx.aggr
         dout = _f32c(dout)
@@ -864,7 +881,7 @@ class PnaConvFn(torch.autograd.Function):
         need_x = ctx.needs_input_grad[0]
         need_att = ctx.needs_input_grad[2] if ctx.mode == "node" else (ctx.needs_input_grad[1] if ctx.mode == "edge" else False)
         if not (need_x or need_att):
-            return None, None, None, dW, db, None, None
+            return None, None, None, dW, db, None, None, None
         dagg = torch.empty(N, F, dtype=f32, device=dev)
         _gemm(0, 0, N, F, Ho, dout, Ho, weight, F, dagg, F)
         tile_ptr, T, rows_nominal, rows_cap, edges_cap, spill = index.pna_tiles(H)
@@ -876,19 +893,19 @@ class PnaConvFn(torch.autograd.Function):
             dw = torch.empty(max(index.E, 1), dtype=f32, device=dev) if need_att else None
             call("gsat_pna_bwd_tiled_node_att", ptr(x), ptr(w), ptr(dagg), ptr(index.rowptr_dst), ptr(index.src_by_dst), ptr(tile_ptr), T,
                  rows_nominal, rows_cap, edges_cap, ptr(index.rowptr_src), ptr(index.slot_dst_of_srcslot), N, index.E, H, a_arr, A, s_arr, 1,
-                 ptr(spill[1:]), ptr(spill[:1]), ptr(dx), ptr(dmsg), ptr(dna), ptr(dw), stream())
+                 ptr(spill[1:]), ptr(spill[:1]), ptr(dx), ptr(dmsg), ptr(dna), ptr(dw), ptr(dx_add), stream())
             dna = dna.view(ctx.att_shape) if need_att else None
         else:
             datt = torch.empty(index.E, dtype=f32, device=dev) if need_att else None
             call("gsat_pna_bwd_tiled", ptr(x), ptr(w) if ctx.mode == "edge" else None, ptr(dagg), ptr(index.rowptr_dst), ptr(index.src_by_dst),
                  ptr(index.eid_by_dst), ptr(tile_ptr), T, rows_nominal, rows_cap, edges_cap, ptr(index.rowptr_src),
                  ptr(index.slot_dst_of_srcslot), N, index.E, H, a_arr, A, s_arr, 1, ptr(spill[1:]), ptr(spill[:1]), ptr(dx), ptr(dmsg),
-                 ptr(datt), stream())
+                 ptr(datt), ptr(dx_add), stream())
             datt = datt.view(ctx.att_shape) if need_att else None
-        return dx, datt, dna, dW, db, None, None
+        return dx, datt, dna, dW, db, None, None, None
 
 
-def pna_conv(x, index, att, edge_emb, aggregators, scalers, avg_deg, weight, bias):
+def pna_conv(x, index, att, edge_emb, aggregators, scalers, avg_deg, weight, bias, passthrough: bool = False):
     """post_nn[0](pna_aggregate(...)) for a PNAConvSimple whose post_nn is one Linear, on the compact aggregate -- opt-in
     (GSAT_PNA_COMPACT=1): measured on MI355X at C3 (profiles/r03_summary.md) the aggregation forward drops from 45 to 24 us per layer
     pass, but the post_nn GEMMs, whose split-bf16 staging is already vector-ALU bound, pay more for rebuilding the x_i columns (forward 65-70
@@ -908,7 +925,7 @@ def pna_conv(x, index, att, edge_emb, aggregators, scalers, avg_deg, weight, bia
             node_att, att = att.node_att, None
         else:
             att = att.edge()
-    return PnaConvFn.apply(x, att, node_att, weight, bias, index, a)
+    return PnaConvFn.apply(x, att, node_att, weight, bias, index, a, passthrough)
 
 
 def linear(x, weight, bias=None):

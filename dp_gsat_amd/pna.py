@@ -1,6 +1,8 @@
 """PNA backbone with the reference's module layout (state_dict-compatible with src/models/pna.py)."""
 from __future__ import annotations
 
+import os
+
 import torch.nn as nn
 import torch.nn.functional as F
 
@@ -55,8 +57,13 @@ class PNA(nn.Module):
             edge_attr = self.edge_encoder(edge_attr)
         for conv, batch_norm in zip(self.convs, self.batch_norms):
             # h = relu(BN(conv)); x = h + x; x = dropout(x)  (src/models/pna.py:57-59) -- one fused pass after the statistics
-            x = batch_norm(conv(x, edge_index, edge_attr, edge_atten=edge_atten, index=index), fused_relu=True, residual=x,
-                           dropout_p=self.dropout_p)
+            # (the conv hands x back as an identity output of its autograd node: the residual's gradient is then added inside the
+            #  aggregation backward, not by a separate [N,H] add per layer)
+            if os.environ.get("GSAT_PNA_RESIDUAL_FOLD", "1") != "0":
+                h, x_res = conv(x, edge_index, edge_attr, edge_atten=edge_atten, index=index, with_residual_input=True)
+            else:
+                h, x_res = conv(x, edge_index, edge_attr, edge_atten=edge_atten, index=index), x
+            x = batch_norm(h, fused_relu=True, residual=x_res, dropout_p=self.dropout_p)
         return x
 
     def forward(self, x, edge_index, batch, edge_attr, edge_atten=None):

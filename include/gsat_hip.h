@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define GSAT_ABI_VERSION 3
+#define GSAT_ABI_VERSION 4
 
 #define GSAT_OK 0
 #define GSAT_ERR_HIP (-1)        /* a HIP runtime call failed */
@@ -251,7 +251,9 @@ int gsat_pna_bwd_tiled(const float* x, const float* att, const float* dout, cons
                        const int32_t* eid, const int32_t* tile_desc, int64_t num_tiles, int rows_nominal, int rows_cap, int edges_cap,
                        const int32_t* rowptr_src, const int32_t* slot_dst_of_srcslot, int64_t num_rows, int64_t num_edges, int64_t H,
                        const int32_t* aggregators, int num_aggregators, const int32_t* scalers, int num_scalers,
-                       const int32_t* spill_rows, const int32_t* spill_count, float* dx, float* dmsg, float* datt, void* stream);
+                       const int32_t* spill_rows, const int32_t* spill_count, float* dx, float* dmsg, float* datt,
+                       const float* dx_add /* [N,H] or NULL: added to dx (a gradient reaching x by another path, e.g. the layer's residual) */,
+                       void* stream);
 
 /*
  * Node attention without the lift (example/gsat.py:112-117 `edge_att = node_att[src] * node_att[dst]`, then PNAConvSimple.message): the
@@ -292,7 +294,7 @@ int gsat_pna_bwd_tiled_node_att(const float* x, const float* node_att, const flo
                                 const int32_t* rowptr_src, const int32_t* slot_dst_of_srcslot, int64_t num_rows, int64_t num_edges, int64_t H,
                                 const int32_t* aggregators, int num_aggregators, const int32_t* scalers, int num_scalers,
                                 const int32_t* spill_rows, const int32_t* spill_count, float* dx, float* dmsg, float* dnode_att, float* dw,
-                                void* stream);
+                                const float* dx_add, void* stream);
 
 /* ================================ BatchNorm1d over node rows ================================= */
 

@@ -370,3 +370,48 @@ def test_pna_conv_on_the_compact_aggregate(dev, monkeypatch, H, Ho, mode):
     for a, b_, what in zip(got, two, ("out", "dx", "datt", "dW", "db")):
         if a is not None:
             close(a, b_, 3e-5, what=what + ": compact vs two-op path")
+
+
+@pytest.mark.parametrize("mode", ["none", "edge", "node"])
+@pytest.mark.parametrize("compact", [False, True])
+def test_pna_residual_gradient_is_added_inside_the_aggregation_backward(dev, monkeypatch, mode, compact):
+    """``conv(..., with_residual_input=True)`` hands x back as an identity output of the aggregation's autograd node; the layer's residual
+    (src/models/pna.py:57-59) then sends its gradient THROUGH that node, whose tiled backward adds it in its own dx pass (dx_add): same
+    gradients as the plain graph (x used twice, autograd adds), and the two paths' dx differ only by the order of one addition."""
+    from dp_gsat_amd.conv_layers import PNAConvSimple
+    from dp_gsat_amd.graph_index import BatchIndex
+    from dp_gsat_amd.ops import LiftedAttention
+    monkeypatch.setattr("dp_gsat_amd.graph_index._HUBS_SEEN", [False])
+    monkeypatch.setenv("GSAT_PNA_COMPACT", "1" if compact else "0")
+    H = 128
+    ei, batch, N = random_batch(77, 40, 1, 40)
+    ei = shuffle_edges(ei, 5)
+    E = ei.shape[1]
+    g = torch.Generator().manual_seed(9)
+    x = torch.randn(N, H, generator=g)
+    att, na = torch.rand(E, 1, generator=g), torch.rand(N, 1, generator=g)
+    deg = torch.bincount(torch.bincount(ei[1], minlength=N))
+    conv = PNAConvSimple(2 * H, H, ["mean", "min", "max", "std"], ["identity"], deg, post_layers=1).to(dev)
+    go = torch.randn(N, H, generator=g).to(dev)
+    gr = torch.randn(N, H, generator=g).to(dev)
+
+    def run(fold):
+        ix = BatchIndex(ei.to(dev), N)
+        ix.graphs(batch.to(dev))
+        xd = x.to(dev).requires_grad_(True)
+        ad = None if mode == "none" else (att if mode == "edge" else na).to(dev).requires_grad_(True)
+        w_e = None if mode == "none" else (ad if mode == "edge" else LiftedAttention(ad, ix))
+        conv.zero_grad(set_to_none=True)
+        if fold:
+            h, x_res = conv(xd, ei.to(dev), None, edge_atten=w_e, index=ix, with_residual_input=True)
+        else:
+            h, x_res = conv(xd, ei.to(dev), None, edge_atten=w_e, index=ix), xd
+        torch.autograd.backward([h, x_res * 1.5], [go, gr])
+        return xd.grad, None if ad is None else ad.grad, conv.post_nn[0].weight.grad.clone()
+
+    a, b = run(True), run(False)
+    for u, v, what in zip(a, b, ("dx", "datt", "dW")):
+        if u is not None:
+            close(u, v, 1e-6, what=what)
+    a2 = run(True)
+    assert torch.equal(a[0], a2[0])

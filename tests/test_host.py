@@ -29,7 +29,7 @@ def test_library_exports_every_declared_symbol():
     for name in sorted(decl):
         assert hasattr(lib, name), f"{name} declared in include/gsat_hip.h but not exported"
     assert decl == set(_lib.SIGNATURES), decl ^ set(_lib.SIGNATURES)
-    assert _lib.load().gsat_abi_version() == 3
+    assert _lib.load().gsat_abi_version() == 4
 
 
 def test_ctypes_structs_match_header_layout():
