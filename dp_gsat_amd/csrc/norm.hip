@@ -5,6 +5,7 @@
 // Statistics are two-pass (mean, then variance of the centred values) with two-stage, fixed-order column sums, so
 // results are bitwise reproducible; running statistics follow torch (momentum update, unbiased running_var).
 #include "common.h"
+#include <cstdlib>
 
 namespace gsat {
 
@@ -39,7 +40,14 @@ __device__ __forceinline__ float4 nslot_reduce(float4 v, float4 (*sm)[NL], int s
 __device__ __forceinline__ float4 block_colsum(const float* __restrict__ part, int RB, int ld, int c, bool on, float4 (*sm)[NL], int slot, int lane) {
     float4 a = f4zero();
     if (on)
-        for (int r = slot; r < RB; r += NS) { float4 t = ld4(part + (size_t)r * ld + c); a.x += t.x; a.y += t.y; a.z += t.z; a.w += t.w; }
+        for (int r0 = slot; r0 < RB; r0 += 8 * NS) {             // eight rows in flight (clamped, masked afterwards), summed in row order
+            float4 t[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) t[j] = ld4(part + (size_t)min(r0 + j * NS, RB - 1) * ld + c);
+#pragma unroll
+            for (int j = 0; j < 8; ++j)
+                if (r0 + j * NS < RB) { a.x += t[j].x; a.y += t[j].y; a.z += t[j].z; a.w += t[j].w; }
+        }
     return nslot_reduce(a, sm, slot, lane);
 }
 
@@ -65,6 +73,89 @@ __global__ __launch_bounds__(NB) void k_bn_partial(const float* __restrict__ x, 
         }
     float4 t = nslot_reduce(acc, sm, slot, lane);
     if (slot == 0 && on) st4(part + (size_t)blockIdx.y * C + c, t);
+}
+
+// One-pass training statistics (round 3): a block takes its rows' mean, then the sum of squares centred on THAT mean (the second sweep re-reads
+// the block's ~200 rows from L2), and leaves (mean_b, M2_b) per channel; k_bn_finalize_chan combines the blocks pairwise-exactly (Chan et al.:
+// delta = mean_b - mean; mean += delta n_b / n; M2 += M2_b + delta^2 n_a n_b / n) in fixed order.  As accurate as the two-pass scheme it
+// replaces (no E[x^2] - mean^2 cancellation), with one sweep over HBM and three launches (partial, finalize, apply) instead of five.
+__global__ __launch_bounds__(NB) void k_bn_partial_chan(const float* __restrict__ x, int64_t N, int C, int64_t rows_per_block, float* __restrict__ part) {
+    __shared__ float4 sm[NS][NL];
+    __shared__ float4 smean[NL];
+    const int lane = threadIdx.x % NL, slot = threadIdx.x / NL;
+    const int c = (blockIdx.x * NL + lane) * 4;
+    const bool on = c < C;
+    const int64_t beg = (int64_t)blockIdx.y * rows_per_block, end = min(N, beg + rows_per_block);
+    const float inv = 1.f / (float)max<int64_t>(end - beg, 1);
+    float4 acc = f4zero();
+    if (on)
+        for (int64_t r = beg + slot; r < end; r += NS) { const float4 v = ld4(x + (size_t)r * C + c); acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w; }
+    float4 t = nslot_reduce(acc, sm, slot, lane);
+    if (slot == 0) smean[lane] = make_float4(t.x * inv, t.y * inv, t.z * inv, t.w * inv);
+    __syncthreads();
+    const float4 mu = smean[lane];
+    acc = f4zero();
+    if (on)
+        for (int64_t r = beg + slot; r < end; r += NS) {
+            const float4 v = ld4(x + (size_t)r * C + c);
+            const float a = v.x - mu.x, b = v.y - mu.y, d = v.z - mu.z, e = v.w - mu.w;
+            acc.x = fmaf(a, a, acc.x); acc.y = fmaf(b, b, acc.y); acc.z = fmaf(d, d, acc.z); acc.w = fmaf(e, e, acc.w);
+        }
+    t = nslot_reduce(acc, sm, slot, lane);
+    if (slot == 0 && on) {
+        st4(part + (size_t)blockIdx.y * 2 * C + c, mu);
+        st4(part + (size_t)blockIdx.y * 2 * C + C + c, t);
+    }
+}
+
+struct Chan4 { float4 mean, m2; float n; };
+__device__ __forceinline__ void chan_add(Chan4& a, float4 mb, float4 m2b, float nb) {
+    if (nb <= 0.f) return;
+    const float tot = a.n + nb, w = nb / tot, u = a.n * w;          // u = n_a n_b / n
+    const float dx = mb.x - a.mean.x, dy = mb.y - a.mean.y, dz = mb.z - a.mean.z, dw = mb.w - a.mean.w;
+    a.mean = make_float4(fmaf(dx, w, a.mean.x), fmaf(dy, w, a.mean.y), fmaf(dz, w, a.mean.z), fmaf(dw, w, a.mean.w));
+    a.m2 = make_float4(a.m2.x + m2b.x + dx * dx * u, a.m2.y + m2b.y + dy * dy * u, a.m2.z + m2b.z + dz * dz * u, a.m2.w + m2b.w + dw * dw * u);
+    a.n = tot;
+}
+__global__ __launch_bounds__(NB) void k_bn_finalize_chan(const float* __restrict__ part, int RB, int64_t N, int64_t rows_per_block, int C, float eps,
+                                                         float momentum, float* __restrict__ mean, float* __restrict__ rstd,
+                                                         float* __restrict__ running_mean, float* __restrict__ running_var) {
+    __shared__ float4 smu[NS][NL], sm2[NS][NL];
+    __shared__ float sn[NS];
+    const int lane = threadIdx.x % NL, slot = threadIdx.x / NL;
+    const int c = (blockIdx.x * NL + lane) * 4;
+    const bool on = c < C;
+    Chan4 a{f4zero(), f4zero(), 0.f};
+    for (int r0 = slot; r0 < RB; r0 += 8 * NS) {                 // blocks slot, slot + 16, ... in order; eight records in flight (clamped loads)
+        float4 mb[8], qb[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int r = min(r0 + j * NS, RB - 1);
+            mb[j] = on ? ld4(part + (size_t)r * 2 * C + c) : f4zero();
+            qb[j] = on ? ld4(part + (size_t)r * 2 * C + C + c) : f4zero();
+        }
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int r = r0 + j * NS;
+            if (r < RB) chan_add(a, mb[j], qb[j], (float)(min(N, (int64_t)(r + 1) * rows_per_block) - (int64_t)r * rows_per_block));
+        }
+    }
+    smu[slot][lane] = a.mean; sm2[slot][lane] = a.m2;
+    if (lane == 0) sn[slot] = a.n;
+    __syncthreads();
+    if (slot != 0 || !on) return;
+    for (int s = 1; s < NS; ++s) chan_add(a, smu[s][lane], sm2[s][lane], sn[s]);          // then the sixteen slot results, in slot order
+    const float inv = 1.f / (float)N;
+    st4(mean + c, a.mean);
+    st4(rstd + c, make_float4(1.f / sqrtf(a.m2.x * inv + eps), 1.f / sqrtf(a.m2.y * inv + eps), 1.f / sqrtf(a.m2.z * inv + eps), 1.f / sqrtf(a.m2.w * inv + eps)));
+    if (running_mean) {
+        const float ub = N > 1 ? 1.f / (float)(N - 1) : inv;
+        const float4 rm = ld4(running_mean + c), rv = ld4(running_var + c);
+        st4(running_mean + c, make_float4((1.f - momentum) * rm.x + momentum * a.mean.x, (1.f - momentum) * rm.y + momentum * a.mean.y,
+                                          (1.f - momentum) * rm.z + momentum * a.mean.z, (1.f - momentum) * rm.w + momentum * a.mean.w));
+        st4(running_var + c, make_float4((1.f - momentum) * rv.x + momentum * a.m2.x * ub, (1.f - momentum) * rv.y + momentum * a.m2.y * ub,
+                                         (1.f - momentum) * rv.z + momentum * a.m2.z * ub, (1.f - momentum) * rv.w + momentum * a.m2.w * ub));
+    }
 }
 
 // STAGE 0: mean = colsum(part)/N ; STAGE 1: rstd = 1/sqrt(colsum(part)/N + eps) and the running-statistics update
@@ -233,10 +324,16 @@ int gsat_bn_act_fwd(const float* x, const float* gamma, const float* beta, float
         float* part1 = workspace + (size_t)RB * C;
         const dim3 grid((unsigned)ceil_div(C, 64), (unsigned)RB);
         const unsigned ct = (unsigned)ceil_div(C, 64);
+        static const int one_pass = getenv("GSAT_BN_ONE_PASS") ? atoi(getenv("GSAT_BN_ONE_PASS")) : 1;
+        if (one_pass) {
+            k_bn_partial_chan<<<grid, NB, 0, stream>>>(x, N, (int)C, rpb, workspace);
+            k_bn_finalize_chan<<<ct, NB, 0, stream>>>(workspace, (int)RB, N, rpb, (int)C, eps, momentum, save_mean, save_rstd, running_mean, running_var);
+        } else {
         k_bn_partial<0><<<grid, NB, 0, stream>>>(x, N, (int)C, rpb, nullptr, part0);
         k_bn_finalize<0><<<ct, NB, 0, stream>>>(part0, (int)RB, N, (int)C, eps, momentum, save_mean, save_rstd, running_mean, running_var);
         k_bn_partial<1><<<grid, NB, 0, stream>>>(x, N, (int)C, rpb, save_mean, part1);
         k_bn_finalize<1><<<ct, NB, 0, stream>>>(part1, (int)RB, N, (int)C, eps, momentum, save_mean, save_rstd, running_mean, running_var);
+        }
     } else {
         GSAT_REQUIRE(running_mean && running_var, GSAT_ERR_ARG, "gsat_bn_fwd: eval mode needs running statistics");
         k_bn_eval_stats<<<(unsigned)ceil_div(C, 256), 256, 0, stream>>>(running_mean, running_var, (int)C, eps, save_mean, save_rstd);
