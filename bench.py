@@ -219,9 +219,14 @@ def aggregation_roofline(wl, data, dev, reps=30, rounds=5, step_fn=None):
         codes = [G.ops.AGGREGATOR_CODES[a] for a in PNA_AGGR]
         a_arr, s_arr = (ctypes.c_int32 * A)(*codes), (ctypes.c_int32 * 1)(0)
         y = torch.empty(N, S * A * 2 * H, device=dev)
+        node_att = not wl["edge_att"]               # the step forms att[row] * att[source] inside the kernels (no lifted [E] tensor): price THAT variant
+        na = torch.rand(N, device=dev)
         def launch():
-            call("gsat_pna_fwd", ptr(x), ptr(att), None, ptr(ix.rowptr_dst), ptr(ix.src_by_dst), ptr(ix.eid_by_dst), N, H,
-                 a_arr, A, s_arr, S, 1.0, 1.0, ptr(y), stream())
+            if node_att:
+                call("gsat_pna_fwd_node_att", ptr(x), ptr(na), ptr(ix.rowptr_dst), ptr(ix.src_by_dst), N, H, a_arr, A, s_arr, S, 1.0, 1.0, ptr(y), stream())
+            else:
+                call("gsat_pna_fwd", ptr(x), ptr(att), None, ptr(ix.rowptr_dst), ptr(ix.src_by_dst), ptr(ix.eid_by_dst), N, H,
+                     a_arr, A, s_arr, S, 1.0, 1.0, ptr(y), stream())
         alg_bytes = 4 * N * H + 8 * A * S * N * H + 8 * E + 4 * N        # SURVEY 8d (unfused PNA forward)
         kname = "k_pna_fwd"
     else:
@@ -303,10 +308,16 @@ def aggregation_roofline(wl, data, dev, reps=30, rounds=5, step_fn=None):
         tiles = ix.pna_tiles(H) if os.environ.get("GSAT_PNA_TILED", "1") != "0" else None
         if tiles:
             tile_desc, T, rows_nominal, rows_cap, edges_cap, spill = tiles
+            dna, dw = torch.empty(N, device=dev), torch.empty(max(E, 1), device=dev)
             def launch_bwd():
-                call("gsat_pna_bwd_tiled", ptr(x), ptr(att), ptr(dout), ptr(ix.rowptr_dst), ptr(ix.src_by_dst), ptr(ix.eid_by_dst),
-                     ptr(tile_desc), T, rows_nominal, rows_cap, edges_cap, ptr(ix.rowptr_src), ptr(ix.slot_dst_of_srcslot), N, E, H,
-                     a_arr, A, s_arr, S, ptr(spill[1:]), ptr(spill[:1]), ptr(dx), ptr(dmsg), ptr(datt), stream())
+                if node_att:
+                    call("gsat_pna_bwd_tiled_node_att", ptr(x), ptr(na), ptr(dout), ptr(ix.rowptr_dst), ptr(ix.src_by_dst), ptr(tile_desc), T,
+                         rows_nominal, rows_cap, edges_cap, ptr(ix.rowptr_src), ptr(ix.slot_dst_of_srcslot), N, E, H, a_arr, A, s_arr, S,
+                         ptr(spill[1:]), ptr(spill[:1]), ptr(dx), ptr(dmsg), ptr(dna), ptr(dw), None, stream())
+                else:
+                    call("gsat_pna_bwd_tiled", ptr(x), ptr(att), ptr(dout), ptr(ix.rowptr_dst), ptr(ix.src_by_dst), ptr(ix.eid_by_dst),
+                         ptr(tile_desc), T, rows_nominal, rows_cap, edges_cap, ptr(ix.rowptr_src), ptr(ix.slot_dst_of_srcslot), N, E, H,
+                         a_arr, A, s_arr, S, ptr(spill[1:]), ptr(spill[:1]), ptr(dx), ptr(dmsg), ptr(datt), None, stream())
             bname = "k_pna_bwd_tile + k_pna_bwd_spill"
         else:
             dx_self = torch.empty(N, H, device=dev)

@@ -60,7 +60,7 @@ for aligned, budget, dbgv in [(True, b, 0) for b in (32768, 40960, 49152, 65536,
         def tiled():
             call("gsat_pna_bwd_tiled", ptr(x), ptr(att), ptr(dout), ptr(ix2.rowptr_dst), ptr(ix2.src_by_dst), ptr(ix2.eid_by_dst),
                  ptr(tile_ptr), T, rows_nominal, rows_cap, edges_cap, ptr(ix2.rowptr_src), ptr(ix2.slot_dst_of_srcslot), N, E, H, a_arr, A, s_arr, 1,
-                 ptr(spill[1:]), ptr(spill[:1]), ptr(dx), ptr(dmsg), ptr(datt), stream())
+                 ptr(spill[1:]), ptr(spill[:1]), ptr(dx), ptr(dmsg), ptr(datt), None, stream())
         t = timeit(tiled)
         err = (dx - ref_dx).abs().max().item()
         print(f"dbg={dbgv:2d} tiled {'aligned' if aligned else 'fixed  '} lds={budget:6d} rows<={rows_cap:3d} edges<={edges_cap:3d} tiles={T:5d} "

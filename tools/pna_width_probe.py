@@ -44,7 +44,7 @@ for H in (32, 64, 80, 96, 128, 160, 256):
     if tiles:
         td, T, rn, rc, ec, spill = tiles
         h = lambda: call("gsat_pna_bwd_tiled", ptr(x), ptr(att), ptr(dout), ptr(ix.rowptr_dst), ptr(ix.src_by_dst), ptr(ix.eid_by_dst), ptr(td), T, rn, rc, ec,
-                         ptr(ix.rowptr_src), ptr(ix.slot_dst_of_srcslot), N, E, H, a_arr, A, s_arr, 1, ptr(spill[1:]), ptr(spill[:1]), ptr(dx), ptr(dmsg), ptr(datt), stream())
+                         ptr(ix.rowptr_src), ptr(ix.slot_dst_of_srcslot), N, E, H, a_arr, A, s_arr, 1, ptr(spill[1:]), ptr(spill[:1]), ptr(dx), ptr(dmsg), ptr(datt), None, stream())
     fb = 4 * N * H + 8 * A * N * H + 8 * E + 4 * N
     bb = 4 * A * 2 * N * H + 8 * N * H + 4 * E * H + 16 * E + 4 * N
     tf, tb = timeit(f), timeit(g)
