@@ -15,6 +15,7 @@ struct FusedGeom {
     int LDX, LDU, LDT, LDH, SW;     // LDS row strides (floats) and the width of a statistics row
     int offU, offT, offS, offMeta;  // LDS offsets (floats)
     int lds_bytes;
+    int pqg;                        // edge mode: P | Q of a tile's nodes go through global memory (no LDS image; tiles limited by edges, not by 64 nodes)
     int x6;                         // layer products as split-bf16 x 6 (hi / mid / lo planes, six MFMAs per 16 k) instead of fp32 MFMA
 };
 
@@ -25,7 +26,7 @@ size_t attn_plan_bytes(int64_t G);
 bool attn_plan_ok(int64_t G);
 int attn_plan_launch(hipStream_t stream, const int32_t* seg_ptr, const int32_t* node_ptr, int64_t G, int RM, int RX, FTile* tiles, int* counters);
 
-bool fused_geometry(int H, int C1, int C2, bool edge, FusedGeom* out);
+bool fused_geometry(int H, int C1, int C2, bool edge, FusedGeom* out, bool pqg = false);
 size_t fused_ws_bytes(const FusedGeom& g, int64_t G);
 bool attn_fused_eligible(const gsat_attn_args* a, FusedGeom* g);
 int attn_fused_fwd(hipStream_t stream, const gsat_attn_args* a, const FusedGeom& g);

@@ -36,7 +36,7 @@ constexpr float F_EPS = 1e-5f;
 // ------------------------------------------------------------------------------------------------
 static inline int ceil32(int v) { return (v + 31) / 32 * 32; }
 
-bool fused_geometry(int H, int C1, int C2, bool edge, FusedGeom* out) {
+bool fused_geometry(int H, int C1, int C2, bool edge, FusedGeom* out, bool pqg) {
     if (H < 8 || H > 256 || H % 8 || C1 < 4 || C1 % 4 || C2 < 4 || C2 % 4 || C2 > 256 || C1 > 2048) return false;
     for (int nrb = 2; nrb >= 1; --nrb) {
         FusedGeom g{};
@@ -47,11 +47,12 @@ bool fused_geometry(int H, int C1, int C2, bool edge, FusedGeom* out) {
         g.NCB2 = g.C2p / 32;
         g.NRB = nrb;
         g.RM = 64 * nrb;
-        g.RX = edge ? 64 : g.RM;
+        g.RX = edge ? (pqg ? g.RM : 64) : g.RM;
+        g.pqg = (edge && pqg) ? 1 : 0;
         g.LDX = H + 4; g.LDU = 2 * g.CH + 4; g.LDT = g.CH + 4; g.LDH = g.C2p + 4;
         g.SW = std::max(g.CH, g.C2p);
         g.offU = g.RX * g.LDX;
-        g.offT = g.offU + (edge ? 64 * g.LDU : 0);
+        g.offT = g.offU + ((edge && !pqg) ? 64 * g.LDU : 0);
         g.offS = std::max(g.offT + g.RM * g.LDT, g.RM * g.LDH);
         const int stats = std::max(2 * F_GT * g.SW, 2 * std::max(C1, C2));      // small tiles: [2][GT][SW]; a big graph: [2][C]
         g.offMeta = g.offS + stats;
@@ -435,7 +436,7 @@ struct FusedArgs {
     FusedGeom g;
 };
 
-template <bool EDGE, int NRB, int NCB2W, bool X6>
+template <bool EDGE, int NRB, int NCB2W, bool X6, bool PQG>
 __global__ __launch_bounds__(FT, 2) void k_attn_fused_fwd(const FusedArgs A) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const FusedGeom& g = A.g;
@@ -489,13 +490,14 @@ __global__ __launch_bounds__(FT, 2) void k_attn_fused_fwd(const FusedArgs A) {
         const bool big = (tl.flags & 1) != 0;
         const int nslab_m = big ? (tl.nrows + RM - 1) / RM : 1;
         if (tid <= tl.ng) sGptr[tid] = A.seg_ptr[tl.g0 + tid] - tl.row0;
+        if (tid == 0) sCtl[1] = 0;                     // set by the meta fill when an edge of the tile has an endpoint outside it
 
         // =========================== big graph, pass 0: P (| Q) of all its nodes -> global ===========================
         // (small tiles run the same GEMM1 code on their single slab inside the chunk loop below)
         auto load_x = [&](int x0, int nx) {            // rows [x0, x0 + nx) of emb -> X, zero-filled to a multiple of 32 rows
             // four 16-byte loads per thread in flight, issued unconditionally (row clamped, zeroed at the LDS store): a load under
             // `r < nx ? load : 0` compiles to a branch that waits for every load before the next one is issued
-            const int fill = min((nx + 31) & ~31, EDGE ? 64 : RM);
+            const int fill = min((nx + 31) & ~31, EDGE ? g.RX : RM);
             for (int i0 = tid; i0 < fill * H4; i0 += 4 * FT) {
                 float4 v[4];
 #pragma unroll
@@ -548,6 +550,48 @@ __global__ __launch_bounds__(FT, 2) void k_attn_fused_fwd(const FusedArgs A) {
                 }
             }
         };
+        // edge mode, P | Q through global memory (g.pqg): layer 1 of chunk kc for the nx node rows in X straight from the accumulators to
+        // P / Q (they are saved for the backward anyway), no LDS image -- a tile is then limited by its 128 EDGES instead of 64 nodes, and the
+        // chunks run back to back as one MFMA stream (one exposed fragment latency per tile instead of one per chunk)
+        auto gemm1_global = [&](int kc, int x0g, int nx) {
+            f32x16 acc0, acc1;
+            acc_zero(acc0); acc_zero(acc1);
+            const float4* bp = A.Wp1 + ((size_t)(kc * 4 + cw) * g.S1) * 64 + lane;
+            const uint4* bx = reinterpret_cast<const uint4*>(A.Wp1) + ((size_t)(kc * 4 + cw) * (H / 16)) * 192 + lane;
+            // row blocks are dealt to the two row-waves alternately (block rw, then rw + 2): a tile of <= 64 nodes keeps both busy
+            const int rbA = rw, rbB = rw + 2;
+            const int na = (rbA * 32 < nx ? 1 : 0) + ((NRB > 1 && rbB * 32 < nx) ? 1 : 0);
+            if (na <= 0) return;
+            if (X6) {
+                const float* a0 = X + (rbA * 32 + c) * LDX + 8 * h;
+                if (na > 1) mma_run_x6<2>(acc0, acc1, a0, a0 + 64 * LDX, bx, H / 16);
+                else mma_run_x6<1>(acc0, acc1, a0, nullptr, bx, H / 16);
+            } else {
+                const float* a0 = X + (rbA * 32 + c) * LDX + h * (H / 2);
+                if (na > 1) mma_run<2>(acc0, acc1, a0, a0 + 64 * LDX, bp, g.S1);
+                else mma_run<1>(acc0, acc1, a0, nullptr, bp, g.S1);
+            }
+            const int col128 = cw * 32 + c, ch = kc * CH + (col128 & (CH - 1));
+            if (ch >= C1) return;
+            // one 64-bit row pointer per block, 32-bit row offsets from an opaque copy of C1: otherwise the compiler hoists the 32 row
+            // addresses (64 registers) out of the chunk loop and the kernel spills
+            int c1o = C1;
+            asm volatile("" : "+s"(c1o));
+            float* const pA = (col128 >= CH ? A.Q : A.P) + ch + (size_t)(x0g + rbA * 32 + 4 * h) * C1;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int rr = (r & 3) + 8 * (r >> 2);
+                if (rbA * 32 + 4 * h + rr < nx) pA[rr * c1o] = acc0[r];
+            }
+            if (na > 1) {
+                float* const pB = pA + (size_t)64 * C1;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int rr = (r & 3) + 8 * (r >> 2);
+                    if (rbB * 32 + 4 * h + rr < nx) pB[rr * c1o] = acc1[r];
+                }
+            }
+        };
         // the chunk just computed -> P (| Q) in global memory, 16-byte rows from LDS (rows [0, nx) of the tile's nodes at global row x0)
         auto save_pq = [&](int kc, int x0, int nx) {
             if (EDGE) {
@@ -565,17 +609,21 @@ __global__ __launch_bounds__(FT, 2) void k_attn_fused_fwd(const FusedArgs A) {
             }
         };
         if (big) {
-            const int RXs = EDGE ? 64 : RM;
+            const int RXs = EDGE ? g.RX : RM;
             for (int x0 = 0; x0 < tl.nnodes; x0 += RXs) {
                 const int nx = min(RXs, tl.nnodes - x0);
                 __syncthreads();
                 load_x(tl.node0 + x0, nx);
                 __syncthreads();
+                if (PQG) {
+                    for (int kc = 0; kc < g.NCH; ++kc) gemm1_global(kc, tl.node0 + x0, nx);
+                } else {
                 for (int kc = 0; kc < g.NCH; ++kc) {
                     gemm1(kc, nx);
                     __syncthreads();
                     save_pq(kc, tl.node0 + x0, nx);
                     __syncthreads();
+                }
                 }
             }
             __syncthreads();          // P / Q of the whole graph are in global memory and visible to this workgroup
@@ -639,6 +687,7 @@ __global__ __launch_bounds__(FT, 2) void k_attn_fused_fwd(const FusedArgs A) {
                         const int sl_ = s - tl.node0, dl_ = d - tl.node0;
                         sSrcL[r] = (!big && (unsigned)sl_ < (unsigned)tl.nnodes) ? sl_ : -(s + 1);
                         sDstL[r] = (!big && (unsigned)dl_ < (unsigned)tl.nnodes) ? dl_ : -(d + 1);
+                        if (!big && ((unsigned)sl_ >= (unsigned)tl.nnodes || (unsigned)dl_ >= (unsigned)tl.nnodes)) sCtl[1] = 1;      // (benign race: every writer stores 1)
                     }
                     int gl = 0;
                     if (!big) {
@@ -655,17 +704,59 @@ __global__ __launch_bounds__(FT, 2) void k_attn_fused_fwd(const FusedArgs A) {
                 for (int i = 0; i < NRB; ++i) acc_zero(acc2[j][i]);
             lds_barrier();
             STAMP(0);
+            if (PQG && !big) {          // P | Q of the tile's nodes, every chunk, straight to global memory; visible to this workgroup after the barrier
+                for (int kc = 0; kc < g.NCH; ++kc) gemm1_global(kc, tl.node0, tl.nnodes);
+                __syncthreads();
+                STAMP(1);
+            }
 
             for (int kc = 0; kc < g.NCH; ++kc) {
                 // ---- layer 1, chunk kc -> T[row][CH] (pre-activation incl. bias) ----------------------------------------
-                if (!big) {
+                if (!big && !PQG) {
                     gemm1(kc, EDGE ? tl.nnodes : tl.nrows);
                     lds_barrier();
                     STAMP(1);
                     save_pq(kc, EDGE ? tl.node0 : tl.row0, EDGE ? tl.nnodes : tl.nrows);
                     STAMP(10);
                 }
-                if (EDGE || big) {
+                if (PQG) {
+                    // P[src] + Q[dst] from global memory (L2: written by this workgroup a moment ago), four rows x two loads in flight per
+                    // thread, unconditional with clamped indices; an endpoint outside the tile (cross-graph edge) is recomputed
+                    constexpr int GB = 2;
+                    for (int i0 = tid; i0 < nrp * CH4; i0 += GB * FT) {
+                        float4 pv[GB], qv[GB];
+#pragma unroll
+                        for (int u = 0; u < GB; ++u) {
+                            const int i = min(i0 + u * FT, nrp * CH4 - 1), r = min(i / CH4, nr - 1), q = i - (i / CH4) * CH4;
+                            const int col = min(kc * CH + 4 * q, C1 - 4);
+                            const int sl_ = sSrcL[r], dl_ = sDstL[r];
+                            const int sg = sl_ >= 0 ? tl.node0 + sl_ : -sl_ - 1, dg = dl_ >= 0 ? tl.node0 + dl_ : -dl_ - 1;
+                            pv[u] = ld4(A.P + (size_t)sg * C1 + col);
+                            qv[u] = ld4(A.Q + (size_t)dg * C1 + col);
+                        }
+#pragma unroll
+                        for (int u = 0; u < GB; ++u) {
+                            const int i = i0 + u * FT;
+                            if (i < nrp * CH4) {
+                                const int r = i / CH4, q = i - r * CH4, col = kc * CH + 4 * q;
+                                st4(T + r * LDT + 4 * q, (r < nr && col < C1) ? f4add(pv[u], qv[u]) : f4zero());
+                            }
+                        }
+                    }
+                    if (!big && sCtl[1] != 0) {          // (rare) endpoints outside the tile: their P / Q rows belong to another workgroup -- recomputed
+                        for (int i = tid; i < nr * CH4; i += FT) {                  // (same item <-> thread map as above: no barrier in between)
+                            const int r = i / CH4, q = i - r * CH4, col = kc * CH + 4 * q;
+                            const int sl_ = sSrcL[r], dl_ = sDstL[r];
+                            if ((sl_ < 0 || dl_ < 0) && col < C1) {
+                                const float4 p4 = sl_ >= 0 ? ld4(A.P + (size_t)(tl.node0 + sl_) * C1 + col) : slow_pq4(A.emb + (size_t)(-sl_ - 1) * H, A.W1, K1, 0, col, C1, H);
+                                const float4 q4 = dl_ >= 0 ? ld4(A.Q + (size_t)(tl.node0 + dl_) * C1 + col) : slow_pq4(A.emb + (size_t)(-dl_ - 1) * H, A.W1, K1, H, col, C1, H);
+                                st4(T + r * LDT + 4 * q, f4add(p4, q4));
+                            }
+                        }
+                    }
+                    lds_barrier();
+                    STAMP(2);
+                } else if (EDGE || big) {
                     for (int i = tid; i < nrp * CH4; i += FT) {
                         const int r = i / CH4, q = i - r * CH4;
                         float4 v = f4zero();
@@ -895,15 +986,15 @@ __global__ __launch_bounds__(FT, 2) void k_attn_fused_fwd(const FusedArgs A) {
 #endif
 }
 
-template <bool EDGE, int NRB, int NCB2W, bool X6 = false>
+template <bool EDGE, int NRB, int NCB2W, bool X6 = false, bool PQG = false>
 static int launch_fused(hipStream_t stream, const FusedArgs& fa, int grid) {
     static size_t allowed = 64 * 1024;
     const size_t lds = (size_t)fa.g.lds_bytes;
     if (lds > allowed) {
-        GSAT_CHECK_HIP(hipFuncSetAttribute((const void*)k_attn_fused_fwd<EDGE, NRB, NCB2W, X6>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        GSAT_CHECK_HIP(hipFuncSetAttribute((const void*)k_attn_fused_fwd<EDGE, NRB, NCB2W, X6, PQG>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         allowed = lds;
     }
-    k_attn_fused_fwd<EDGE, NRB, NCB2W, X6><<<grid, FT, lds, stream>>>(fa);
+    k_attn_fused_fwd<EDGE, NRB, NCB2W, X6, PQG><<<grid, FT, lds, stream>>>(fa);
     GSAT_LAUNCH_CHECK();
     return GSAT_OK;
 }
@@ -927,7 +1018,11 @@ bool attn_fused_eligible(const gsat_attn_args* a, FusedGeom* g) {
     if (a->M <= 0 || a->G <= 0 || a->G > (int64_t)PLAN_MAX_SB * 64) return false;
     if (!a->edge_mode && a->seg_order) return false;
     if (a->edge_mode && !a->node_ptr) return false;
-    if (!fused_geometry(a->H, a->C1, a->C2, a->edge_mode != 0, g)) return false;
+    {   // edge mode: P | Q of a tile's nodes through global memory (tiles limited by 128 EDGES, not 64 nodes) unless GSAT_ATTN_FUSED_PQG=0
+        const char* ep = getenv("GSAT_ATTN_FUSED_PQG");
+        const bool pqg = a->edge_mode && !(ep && atoi(ep) == 0);
+        if (!(pqg && fused_geometry(a->H, a->C1, a->C2, true, g, true) && g->NRB == 2) && !fused_geometry(a->H, a->C1, a->C2, a->edge_mode != 0, g, false)) return false;
+    }
     {   // split-bf16 x 6 products (GSAT_ATTN_FUSED_X6=0: exact fp32 MFMA): the common tile shape only, K a multiple of 16
         const char* ex = getenv("GSAT_ATTN_FUSED_X6");
         g->x6 = (!(ex && atoi(ex) == 0) && a->H % 16 == 0 && g->NRB == 2 && g->NCB2 <= 4) ? 1 : 0;
@@ -975,6 +1070,11 @@ int attn_fused_fwd(hipStream_t stream, const gsat_attn_args* a, const FusedGeom&
     const bool e = a->edge_mode != 0;
     const int ncbw = g.NCB2 > 4 ? 2 : 1;
 #define GO(E, R, W) return launch_fused<E, R, W>(stream, fa, grid)
+    if (e && g.pqg) {            // P | Q through global memory: NRB = 2 by construction
+        if (g.x6) return launch_fused<true, 2, 1, true, true>(stream, fa, grid);
+        if (ncbw == 2) return launch_fused<true, 2, 2, false, true>(stream, fa, grid);
+        return launch_fused<true, 2, 1, false, true>(stream, fa, grid);
+    }
     if (g.x6) { if (e) return launch_fused<true, 2, 1, true>(stream, fa, grid); return launch_fused<false, 2, 1, true>(stream, fa, grid); }
     if (e) { if (g.NRB == 2) { if (ncbw == 2) GO(true, 2, 2); GO(true, 2, 1); } if (ncbw == 2) GO(true, 1, 2); GO(true, 1, 1); }
     if (g.NRB == 2) { if (ncbw == 2) GO(false, 2, 2); GO(false, 2, 1); }
