@@ -185,6 +185,7 @@ class PnaAggregate(torch.autograd.Function):
         # layer's residual, src/models/pna.py:57-59 -- has that path's gradient arrive HERE, where the tiled backward adds it inside its
         # own dx pass (dx_add) instead of autograd launching one [N,H] add per layer.
         import ctypes
+        ctx.set_materialize_grads(False)          # (out, x) outputs: an unused one arrives as None in backward
         x_in = x
         x = _f32c(x)
         ctx.passthrough = bool(passthrough)
@@ -373,6 +374,7 @@ class ExtractorAttention(torch.autograd.Function):
     @staticmethod
     def forward(ctx, emb, W1, b1, W2, b2, W3, b3, index, segments, edge_mode, training, p, seed, mask1, mask2, u, seed_dev=None, noise_philox=False):
         import ctypes
+        ctx.set_materialize_grads(False)          # an unused output (the logits, normally) arrives as None in backward, not as a zero-filled [M,1] tensor
         emb = _f32c(emb)
         params = tuple(_f32c(t) for t in (W1, b1, W2, b2, W3, b3))
         mask1, mask2 = _f32c(mask1), _f32c(mask2)
@@ -822,6 +824,7 @@ class PnaConvFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, att, node_att, weight, bias, index: BatchIndex, aggr_codes, passthrough: bool = False):
         import ctypes
+        ctx.set_materialize_grads(False)
         x_in = x
         ctx.passthrough = bool(passthrough)
         x, weight = _f32c(x), _f32c(weight)
