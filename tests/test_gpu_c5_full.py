@@ -81,7 +81,7 @@ def test_c5_aggregation_fwd_bwd_h256(c5):
     assert torch.equal(od2.detach(), out) and torch.equal(xd2.grad, dx) and torch.equal(ad2.grad, da)     # bitwise reproducible
     del od, od2, xd2, ad2
     got = (out, dx, da)
-    for dt, tol in ((torch.float64, 1e-4), (torch.float32, 2e-4)):          # fp64 ATen is the yardstick; fp32 ATen (atomics) is looser
+    for dt, tol in ((torch.float64, 1e-4), (torch.float32, 1e-4)):          # fp64 ATen is the yardstick; fp32 ATen (atomics) is looser
         xo, ao = x.to(dt).requires_grad_(True), att.to(dt).requires_grad_(True)
         oo = oops.gin_aggregate(xo, data.edge_index, ao)
         oo.backward(go.to(dt))
@@ -138,4 +138,4 @@ def test_c5_extractor_h256_whole_graphs_out_of_the_batch(c5):
         r32, r64 = ref[torch.float32], ref[torch.float64]
         close(z.detach()[sel_d], r32[0], ref64=r64[0], what=f"logits of graph {gid}")
         close(att.detach()[sel_d], r32[1], ref64=r64[1], what=f"att of graph {gid}")
-        close(demb[n0:n1], r32[2], 2e-4, ref64=r64[2], what=f"demb of graph {gid}")
+        close(demb[n0:n1], r32[2], 1e-4, ref64=r64[2], what=f"demb of graph {gid}")

@@ -83,7 +83,7 @@ def _worker(rank, world, port, backbone, edge_att, q):
                 scale = max(1.0, float(ref[k].abs().max()))
                 err = float((p.grad - ref[k]).abs().max()) / scale
                 worst = max(worst, err)
-                ok = ok and err <= 2e-4 and p.grad.data_ptr() >= flat.flat.data_ptr()
+                ok = ok and err <= 1e-4 and p.grad.data_ptr() >= flat.flat.data_ptr()
         bn_err = max([float((gsat2.state_dict()[k] - v).abs().max()) for k, v in bn_ref.items()] + [0.0])
         loss_err = abs(float(tot) / world - float(loss_ref))
         q.put((rank, ok and bn_err < 1e-5 and loss_err < 1e-5, worst, bn_err, loss_err, work is not None))

@@ -53,4 +53,4 @@ def test_dual_forward_pass(dev, epoch, training):
         o_loss.backward(); loss.backward()
         for (k, p), (_, q) in zip(list(pc.named_parameters()) + list(de.named_parameters()), list(opc.named_parameters()) + list(ode.named_parameters())):
             if q.grad is not None:
-                close(p.grad, q.grad, 2e-4, what=k)
+                close(p.grad, q.grad, 1e-4, what=k)

@@ -58,7 +58,7 @@ def _step(G, data, oclf, oext, clf, ext, learn_edge_att, H, dev, training=True, 
             if q.grad is None:
                 assert p.grad is None or float(p.grad.abs().max()) == 0.0, k
                 continue
-            close(p.grad, q.grad, 2e-4, ref64=q64.grad, what="grad " + k)
+            close(p.grad, q.grad, 1e-4, ref64=q64.grad, what="grad " + k)
 
 
 @pytest.mark.parametrize("training", [True, False])
@@ -133,9 +133,9 @@ def test_against_committed_golden(dev, name, backbone, edge):
     assert abs(ld["loss"] - c["loss"].item()) < 1e-4 and abs(ld["info"] - c["info"].item()) < 1e-4
     loss.backward()
     for k, p in ext.named_parameters():
-        close(p.grad, c["grad.ext." + k], 2e-4, what="grad ext." + k)
+        close(p.grad, c["grad.ext." + k], 1e-4, what="grad ext." + k)
     for k, p in clf.named_parameters():
-        close(p.grad, c["grad.clf." + k], 2e-4, what="grad clf." + k)
+        close(p.grad, c["grad.clf." + k], 1e-4, what="grad clf." + k)
 
 
 def test_backbone_dropout_and_unmasked_call_forms(dev):

@@ -113,9 +113,9 @@ def test_pna_with_edge_attr(dev, H, aggr):
     od.backward(go.to(dev))
     r32, r64 = ref[torch.float32], ref[torch.float64]
     close(od, r32[0], ref64=r64[0], what="out")
-    close(xd.grad, r32[1], 2e-4, ref64=r64[1], what="dx")
-    close(ed.grad, r32[2], 2e-4, ref64=r64[2], what="dedge")
-    close(ad.grad, r32[3], 2e-4, ref64=r64[3], what="datt")
+    close(xd.grad, r32[1], 1e-4, ref64=r64[1], what="dx")
+    close(ed.grad, r32[2], 1e-4, ref64=r64[2], what="dedge")
+    close(ad.grad, r32[3], 1e-4, ref64=r64[3], what="datt")
 
 
 def test_pna_empty_rows_std(dev):
