@@ -313,7 +313,7 @@ def aggregation_roofline(wl, data, dev, reps=30, rounds=5, step_fn=None):
                 if node_att:
                     call("gsat_pna_bwd_tiled_node_att", ptr(x), ptr(na), ptr(dout), ptr(ix.rowptr_dst), ptr(ix.src_by_dst), ptr(tile_desc), T,
                          rows_nominal, rows_cap, edges_cap, ptr(ix.rowptr_src), ptr(ix.slot_dst_of_srcslot), N, E, H, a_arr, A, s_arr, S,
-                         ptr(spill[1:]), ptr(spill[:1]), ptr(dx), ptr(dmsg), ptr(dna), ptr(dw), None, stream())
+                         ptr(spill[1:]), ptr(spill[:1]), ptr(dx), ptr(dmsg), ptr(dna), ptr(dw), None, 0, stream())
                 else:
                     call("gsat_pna_bwd_tiled", ptr(x), ptr(att), ptr(dout), ptr(ix.rowptr_dst), ptr(ix.src_by_dst), ptr(ix.eid_by_dst),
                          ptr(tile_desc), T, rows_nominal, rows_cap, edges_cap, ptr(ix.rowptr_src), ptr(ix.slot_dst_of_srcslot), N, E, H,

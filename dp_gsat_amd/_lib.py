@@ -45,7 +45,7 @@ SIGNATURES = {
     "gsat_pna_post_dw_workspace_floats": (SZ, [I64, I64, INT, I64]),
     "gsat_pna_post_dw": (INT, [P, P, P, I64, I64, INT, P, I64, P, P, SZ, P]),
     "gsat_pna_fwd_node_att": (INT, [P, P, P, P, I64, I64, P, INT, P, INT, F32, F32, P, P]),
-    "gsat_pna_bwd_tiled_node_att": (INT, [P, P, P, P, P, P, I64, INT, INT, INT, P, P, I64, I64, I64, P, INT, P, INT, P, P, P, P, P, P, P, P]),
+    "gsat_pna_bwd_tiled_node_att": (INT, [P, P, P, P, P, P, I64, INT, INT, INT, P, P, I64, I64, I64, P, INT, P, INT, P, P, P, P, P, P, P, INT, P]),
     "gsat_csr_pair_workspace_bytes": (SZ, [I64, I64]),
     "gsat_build_csr_pair": (INT, [P, I64, I64] + [P] * 12 + [P, SZ, P]),
     "gsat_segment_ptr32": (INT, [P, I64, I64, P, P, P, P]),

@@ -686,7 +686,7 @@ __global__ __launch_bounds__(TILE_BLOCK, 4) void k_pna_bwd_tile(
     const float* __restrict__ x, const float* __restrict__ att, const float* __restrict__ dout, const int32_t* __restrict__ rowptr,
     const int32_t* __restrict__ col, const int32_t* __restrict__ eid, const int4* __restrict__ desc,
     const int32_t* __restrict__ rowptr_src, const int32_t* __restrict__ slot_map, int H, int TE, int RCAP, float* dx,
-    float* __restrict__ dmsg, float* datt, float* __restrict__ dw, const float* __restrict__ dx_add) {
+    float* __restrict__ dmsg, float* datt, float* __restrict__ dw, const float* __restrict__ dx_add, int datt_acc) {
     constexpr int GPB = LaneGroups<LPR, TILE_BLOCK>::GPB;     // lane groups (rows in flight) per workgroup
     constexpr int RPW = 64 / LPR;                // rows covered by one wave-instruction
     constexpr int NSEG = NAGG * 2;
@@ -884,6 +884,8 @@ __global__ __launch_bounds__(TILE_BLOCK, 4) void k_pna_bwd_tile(
         if (!on) continue;
         const int sb = s_rps[j - n0], se = s_rps[j - n0 + 1];
         float4 acc = ld4(dx + (size_t)j * H + c);
+        // NATT, datt_acc: d node_att is shared by every layer that used the attention: this launch adds its share to what is there
+        const float dprev = (NATT && datt && datt_acc && lane == 0) ? datt[j] : 0.f;
         if (dx_add) {              // a gradient that reaches x by another path (the layer's residual): added here instead of by a separate kernel
             const float4 r = ld4(dx_add + (size_t)j * H + c);
             acc.x += r.x; acc.y += r.y; acc.z += r.z; acc.w += r.w;
@@ -898,7 +900,7 @@ __global__ __launch_bounds__(TILE_BLOCK, 4) void k_pna_bwd_tile(
             }
         }
         st4(dx + (size_t)j * H + c, acc);
-        if (NATT && datt && lane == 0) datt[j] = s_dna[j - n0] + sw;      // destination share (this lane's own LDS store of the row loop) + source share
+        if (NATT && datt && lane == 0) datt[j] = (s_dna[j - n0] + sw) + dprev;      // destination share (this lane's own LDS store of the row loop) + source share
     }
 }
 
@@ -1211,7 +1213,7 @@ static int pna_bwd_tiled_impl(const char* who, bool natt, const float* x, const 
                               int rows_cap, int edges_cap, const int32_t* rowptr_src, const int32_t* slot_dst_of_srcslot, int64_t N,
                               int64_t E, int64_t H, const int32_t* aggregators, int A, const int32_t* scalers, int S,
                               const int32_t* spill_rows, const int32_t* spill_count, float* dx, float* dmsg, float* datt, float* dw,
-                              const float* dx_add, hipStream_t stream) {
+                              const float* dx_add, int datt_acc, hipStream_t stream) {
     GSAT_REQUIRE(N >= 0 && N < (1ll << 31) && E >= 0 && num_tiles >= 0, GSAT_ERR_ARG, "%s: bad extents", who);
     PnaCfg cfg;
     int rc = make_cfg(aggregators, A, scalers, S, 1.f, 1.f, &cfg);
@@ -1230,7 +1232,7 @@ static int pna_bwd_tiled_impl(const char* who, bool natt, const float* x, const 
     do {                                                                                                                     \
         GSAT_CHECK_HIP((pna_tile_allow_lds<L, NA, NT>(lds)));                                                                \
         k_pna_bwd_tile<L, NA, NT><<<(int)num_tiles, TILE_BLOCK, lds, stream>>>(x, att, dout, rowptr, col, eid, (const int4*)tile_desc,     \
-                                                                          rowptr_src, slot_dst_of_srcslot, (int)H, edges_cap, rows_cap, dx, dmsg, datt, dw, dx_add); \
+                                                                          rowptr_src, slot_dst_of_srcslot, (int)H, edges_cap, rows_cap, dx, dmsg, datt, dw, dx_add, datt_acc); \
     } while (0)
 #define CALL(L) do { if (natt) { if (nagg == 4) GO(L, 4, true); else GO(L, 5, true); } else { if (nagg == 4) GO(L, 4, false); else GO(L, 5, false); } } while (0)
     if (num_tiles > 0) { GSAT_LPR_DISPATCH(lpr, CALL); }
@@ -1257,7 +1259,7 @@ int gsat_pna_bwd_tiled(const float* x, const float* att, const float* dout, cons
                        const int32_t* spill_count, float* dx, float* dmsg, float* datt, const float* dx_add, void* stream_) {
     return pna_bwd_tiled_impl("gsat_pna_bwd_tiled", false, x, att, dout, rowptr, col, eid, tile_desc, num_tiles, rows_nominal, rows_cap, edges_cap,
                               rowptr_src, slot_dst_of_srcslot, N, E, H, aggregators, A, scalers, S, spill_rows, spill_count, dx, dmsg, datt,
-                              nullptr, dx_add, (hipStream_t)stream_);
+                              nullptr, dx_add, 0, (hipStream_t)stream_);
 }
 
 int gsat_pna_bwd_tiled_node_att(const float* x, const float* node_att, const float* dout, const int32_t* rowptr, const int32_t* col,
@@ -1265,10 +1267,10 @@ int gsat_pna_bwd_tiled_node_att(const float* x, const float* node_att, const flo
                                 const int32_t* rowptr_src, const int32_t* slot_dst_of_srcslot, int64_t N, int64_t E, int64_t H,
                                 const int32_t* aggregators, int A, const int32_t* scalers, int S, const int32_t* spill_rows,
                                 const int32_t* spill_count, float* dx, float* dmsg, float* dnode_att, float* dw, const float* dx_add,
-                                void* stream_) {
+                                int accumulate_dnode_att, void* stream_) {
     return pna_bwd_tiled_impl("gsat_pna_bwd_tiled_node_att", true, x, node_att, dout, rowptr, col, nullptr, tile_desc, num_tiles, rows_nominal,
                               rows_cap, edges_cap, rowptr_src, slot_dst_of_srcslot, N, E, H, aggregators, A, scalers, S, spill_rows, spill_count,
-                              dx, dmsg, dnode_att, dw, dx_add, (hipStream_t)stream_);
+                              dx, dmsg, dnode_att, dw, dx_add, accumulate_dnode_att, (hipStream_t)stream_);
 }
 
 }  // extern "C"

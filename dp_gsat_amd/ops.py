@@ -45,6 +45,27 @@ class LiftedAttention:
         if node_att.numel() != index.N:
             raise ValueError("node attention must have one entry per node")
         self.node_att, self.index, self._edge = node_att, index, None
+        # the layers that form the attention inside their kernels share ONE d node_att buffer: they all read `shared_node_att`, an identity
+        # output of one autograd node (_SharedAttention) that only they consume; the first of their backward nodes to run writes the
+        # buffer and hands it to autograd, the others add to it inside their own kernel and return nothing (no [N,1] add launch per
+        # layer); _SharedAttention.backward runs after all of them, passes the sum on to node_att (where autograd may add other consumers'
+        # gradients, e.g. the info loss) and clears the state for a second backward through a retained graph.
+        self._dna = None
+        self._shared = None
+
+    @property
+    def shared_node_att(self) -> torch.Tensor:
+        if self._shared is None:
+            self._shared = _SharedAttention.apply(self.node_att, self)
+        return self._shared
+
+    def _shared_dna(self, N, device):
+        """(buffer, accumulate, what to return to autograd) for one layer's d node_att."""
+        if self._dna is None or os.environ.get("GSAT_NODE_ATT_SHARED_GRAD", "1") == "0":
+            buf = torch.empty(N, dtype=torch.float32, device=device)
+            self._dna = buf if os.environ.get("GSAT_NODE_ATT_SHARED_GRAD", "1") != "0" else None
+            return buf, 0, buf
+        return self._dna, 1, None
 
     def edge(self) -> torch.Tensor:
         if self._edge is None:
@@ -71,6 +92,21 @@ class LiftedAttention:
 
     def __repr__(self):
         return f"LiftedAttention(nodes={self.index.N}, edges={self.index.E}, materialised={self._edge is not None})"
+
+
+class _SharedAttention(torch.autograd.Function):
+    """Identity on node_att whose output is consumed only by the aggregation layers that form the lifted attention in their kernels
+    (LiftedAttention.shared_node_att): its backward sees their in-kernel sum as ONE gradient."""
+
+    @staticmethod
+    def forward(ctx, node_att, owner):
+        ctx.owner = owner
+        return node_att.view_as(node_att)
+
+    @staticmethod
+    def backward(ctx, grad):
+        ctx.owner._dna = None
+        return grad, None
 
 
 def edge_tensor(att):
@@ -180,7 +216,7 @@ class PnaAggregate(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, att, edge_emb, index: BatchIndex, aggr_codes, scaler_codes, avg_lin: float, avg_log: float, node_att=None,
-                passthrough: bool = False):
+                passthrough: bool = False, lifted=None):
         # passthrough: ALSO return x itself (an identity output of this node).  A caller that feeds it to a second consumer of x -- the
         # layer's residual, src/models/pna.py:57-59 -- has that path's gradient arrive HERE, where the tiled backward adds it inside its
         # own dx pass (dx_add) instead of autograd launching one [N,H] add per layer.
@@ -189,6 +225,7 @@ class PnaAggregate(torch.autograd.Function):
         x_in = x
         x = _f32c(x)
         ctx.passthrough = bool(passthrough)
+        ctx.lifted = lifted
         if node_att is not None:
             out = PnaAggregate._forward_node_att(ctx, x, node_att, index, aggr_codes, scaler_codes, avg_lin, avg_log)
             return (out, x_in) if passthrough else out
@@ -256,19 +293,24 @@ class PnaAggregate(torch.autograd.Function):
         tile_ptr, T, rows_nominal, rows_cap, edges_cap, spill = index.pna_tiles(H)
         dmsg = torch.empty(max(index.E, 1), H, dtype=torch.float32, device=dev)[: index.E]
         dw = torch.empty(max(index.E, 1), dtype=torch.float32, device=dev) if need_att else None
-        dna = torch.empty(N, dtype=torch.float32, device=dev) if need_att else None
+        dna, acc, ret = None, 0, None
+        if need_att:
+            if ctx.lifted is not None:
+                dna, acc, ret = ctx.lifted._shared_dna(N, dev)
+            else:
+                dna = ret = torch.empty(N, dtype=torch.float32, device=dev)
         dx = torch.empty_like(x)
         call("gsat_pna_bwd_tiled_node_att", ptr(x), ptr(na), ptr(dout), ptr(index.rowptr_dst), ptr(index.src_by_dst), ptr(tile_ptr), T,
              rows_nominal, rows_cap, edges_cap, ptr(index.rowptr_src), ptr(index.slot_dst_of_srcslot), N, index.E, H, a_arr, A, s_arr, S,
-             ptr(spill[1:]), ptr(spill[:1]), ptr(dx), ptr(dmsg), ptr(dna), ptr(dw), ptr(dx_add), stream())
-        return dx, None, None, None, None, None, None, None, (dna.view(ctx.att_shape) if need_att else None), None
+             ptr(spill[1:]), ptr(spill[:1]), ptr(dx), ptr(dmsg), ptr(dna), ptr(dw), ptr(dx_add), acc, stream())
+        return dx, None, None, None, None, None, None, None, (ret.view(ctx.att_shape) if ret is not None else None), None, None
 
     @staticmethod
     def backward(ctx, dout, dx_add=None):
         import ctypes
         dx_add = None if dx_add is None else _f32c(dx_add)
         if dout is None:                       # only the identity output was used
-            return dx_add, None, None, None, None, None, None, None, None, None
+            return dx_add, None, None, None, None, None, None, None, None, None, None
         if ctx.node_att:
             return PnaAggregate._backward_node_att(ctx, dout, dx_add)
         x, attf, edge_emb = ctx.saved_tensors
@@ -299,7 +341,7 @@ class PnaAggregate(torch.autograd.Function):
             call("gsat_pna_bwd_tiled", ptr(x), ptr(attf), ptr(dout), ptr(index.rowptr_dst), ptr(index.src_by_dst), ptr(index.eid_by_dst),
                  ptr(tile_ptr), T, rows_nominal, rows_cap, edges_cap, ptr(index.rowptr_src), ptr(index.slot_dst_of_srcslot), N, index.E, H,
                  a_arr, A, s_arr, S, ptr(spill[1:]), ptr(spill[:1]), ptr(dx), ptr(dmsg), ptr(datt), ptr(dx_add), stream())
-            return dx, (datt.view(ctx.att_shape) if need_att else None), None, None, None, None, None, None, None, None
+            return dx, (datt.view(ctx.att_shape) if need_att else None), None, None, None, None, None, None, None, None, None
         dx_self = torch.empty_like(x)
         dee = torch.empty_like(edge_emb) if need_ee else None
         if hubs is not None:
@@ -317,7 +359,7 @@ class PnaAggregate(torch.autograd.Function):
              ptr(index.long_rows[1]), ptr(index.partial(H)) if index.long_rows[1] is not None else None, stream())
         if dx_add is not None:
             dx = dx + dx_add
-        return dx, (datt.view(ctx.att_shape) if need_att else None), dee, None, None, None, None, None, None, None
+        return dx, (datt.view(ctx.att_shape) if need_att else None), dee, None, None, None, None, None, None, None, None
 
 
 def pna_aggregate(x, index, att, edge_emb, aggregators, scalers, avg_deg, passthrough: bool = False):
@@ -329,7 +371,7 @@ def pna_aggregate(x, index, att, edge_emb, aggregators, scalers, avg_deg, passth
         if (edge_emb is None and att.index is index and _FIXED_PNA.get((tuple(a), tuple(s))) and index.long_rows_nowait[0] is None
                 and os.environ.get("GSAT_PNA_TILED", "1") != "0" and os.environ.get("GSAT_NODE_ATT_LIFT", "0") != "1"
                 and att._edge is None and index.pna_tiles(x.shape[1])):
-            return PnaAggregate.apply(x, None, None, index, a, s, avg_deg["lin"], avg_deg["log"], att.node_att, passthrough)
+            return PnaAggregate.apply(x, None, None, index, a, s, avg_deg["lin"], avg_deg["log"], att.shared_node_att, passthrough, att)
         att = att.edge()
     return PnaAggregate.apply(x, att, edge_emb, index, a, s, avg_deg["lin"], avg_deg["log"], None, passthrough)
 
@@ -822,9 +864,10 @@ class PnaConvFn(torch.autograd.Function):
     saved activation.  Edge weights: none, an [E] tensor, or node attention formed inside the kernels."""
 
     @staticmethod
-    def forward(ctx, x, att, node_att, weight, bias, index: BatchIndex, aggr_codes, passthrough: bool = False):
+    def forward(ctx, x, att, node_att, weight, bias, index: BatchIndex, aggr_codes, passthrough: bool = False, lifted=None):
         import ctypes
         ctx.set_materialize_grads(False)
+        ctx.lifted = lifted
         x_in = x
         ctx.passthrough = bool(passthrough)
         x, weight = _f32c(x), _f32c(weight)
@@ -863,7 +906,7 @@ class PnaConvFn(torch.autograd.Function):
         from ._lib import load
         dx_add = None if dx_add is None else _f32c(dx_add)
         if dout is None:
-            return dx_add, None, None, None, None, None, None, None
+            return dx_add, None, None, None, None, None, None, None, None
         x, w, aggj, scal, weight = ctx.saved_tensors
         index, aggr_codes = ctx.index, ctx.aggr
         dout = _f32c(dout)
@@ -884,7 +927,7 @@ class PnaConvFn(torch.autograd.Function):
         need_x = ctx.needs_input_grad[0]
         need_att = ctx.needs_input_grad[2] if ctx.mode == "node" else (ctx.needs_input_grad[1] if ctx.mode == "edge" else False)
         if not (need_x or need_att):
-            return None, None, None, dW, db, None, None, None
+            return None, None, None, dW, db, None, None, None, None
         dagg = torch.empty(N, F, dtype=f32, device=dev)
         _gemm(0, 0, N, F, Ho, dout, Ho, weight, F, dagg, F)
         tile_ptr, T, rows_nominal, rows_cap, edges_cap, spill = index.pna_tiles(H)
@@ -892,12 +935,17 @@ class PnaConvFn(torch.autograd.Function):
         dx = torch.empty_like(x)
         datt = dna = None
         if ctx.mode == "node":
-            dna = torch.empty(N, dtype=f32, device=dev) if need_att else None
+            dna, acc, ret = None, 0, None
+            if need_att:
+                if ctx.lifted is not None:
+                    dna, acc, ret = ctx.lifted._shared_dna(N, dev)
+                else:
+                    dna = ret = torch.empty(N, dtype=f32, device=dev)
             dw = torch.empty(max(index.E, 1), dtype=f32, device=dev) if need_att else None
             call("gsat_pna_bwd_tiled_node_att", ptr(x), ptr(w), ptr(dagg), ptr(index.rowptr_dst), ptr(index.src_by_dst), ptr(tile_ptr), T,
                  rows_nominal, rows_cap, edges_cap, ptr(index.rowptr_src), ptr(index.slot_dst_of_srcslot), N, index.E, H, a_arr, A, s_arr, 1,
-                 ptr(spill[1:]), ptr(spill[:1]), ptr(dx), ptr(dmsg), ptr(dna), ptr(dw), ptr(dx_add), stream())
-            dna = dna.view(ctx.att_shape) if need_att else None
+                 ptr(spill[1:]), ptr(spill[:1]), ptr(dx), ptr(dmsg), ptr(dna), ptr(dw), ptr(dx_add), acc, stream())
+            dna = ret.view(ctx.att_shape) if ret is not None else None
         else:
             datt = torch.empty(index.E, dtype=f32, device=dev) if need_att else None
             call("gsat_pna_bwd_tiled", ptr(x), ptr(w) if ctx.mode == "edge" else None, ptr(dagg), ptr(index.rowptr_dst), ptr(index.src_by_dst),
@@ -905,7 +953,7 @@ class PnaConvFn(torch.autograd.Function):
                  ptr(index.slot_dst_of_srcslot), N, index.E, H, a_arr, A, s_arr, 1, ptr(spill[1:]), ptr(spill[:1]), ptr(dx), ptr(dmsg),
                  ptr(datt), ptr(dx_add), stream())
             datt = datt.view(ctx.att_shape) if need_att else None
-        return dx, datt, dna, dW, db, None, None, None
+        return dx, datt, dna, dW, db, None, None, None, None
 
 
 def pna_conv(x, index, att, edge_emb, aggregators, scalers, avg_deg, weight, bias, passthrough: bool = False):
@@ -922,13 +970,13 @@ def pna_conv(x, index, att, edge_emb, aggregators, scalers, avg_deg, weight, bia
             and os.environ.get("GSAT_PNA_TILED", "1") != "0" and index.long_rows_nowait[0] is None
             and (bias is None or bias.data_ptr() % 16 == 0) and index.pna_tiles(H)):
         return None
-    node_att = None
+    node_att = lifted = None
     if isinstance(att, LiftedAttention):
         if att.index is index and att._edge is None and os.environ.get("GSAT_NODE_ATT_LIFT", "0") != "1":
-            node_att, att = att.node_att, None
+            node_att, lifted, att = att.shared_node_att, att, None
         else:
             att = att.edge()
-    return PnaConvFn.apply(x, att, node_att, weight, bias, index, a, passthrough)
+    return PnaConvFn.apply(x, att, node_att, weight, bias, index, a, passthrough, lifted)
 
 
 def linear(x, weight, bias=None):

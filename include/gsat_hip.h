@@ -294,7 +294,8 @@ int gsat_pna_bwd_tiled_node_att(const float* x, const float* node_att, const flo
                                 const int32_t* rowptr_src, const int32_t* slot_dst_of_srcslot, int64_t num_rows, int64_t num_edges, int64_t H,
                                 const int32_t* aggregators, int num_aggregators, const int32_t* scalers, int num_scalers,
                                 const int32_t* spill_rows, const int32_t* spill_count, float* dx, float* dmsg, float* dnode_att, float* dw,
-                                const float* dx_add, void* stream);
+                                const float* dx_add, int accumulate_dnode_att /* 1: dnode_att += (the layers of a model share one attention) */,
+                                void* stream);
 
 /* ================================ BatchNorm1d over node rows ================================= */
 

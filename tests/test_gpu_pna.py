@@ -415,3 +415,42 @@ def test_pna_residual_gradient_is_added_inside_the_aggregation_backward(dev, mon
             close(u, v, 1e-6, what=what)
     a2 = run(True)
     assert torch.equal(a[0], a2[0])
+
+
+def test_layers_share_one_node_attention_gradient(dev, monkeypatch):
+    """Three aggregation layers on one lifted node attention + another consumer of the same node_att (as the info loss is): the layers add
+    their shares of d node_att inside their kernels into one buffer (no [N,1] add launch per layer), autograd adds the other consumer's
+    gradient on top; equal to the per-layer buffers bit for bit in the layers' part (same kernels, a different place for the adds) within
+    fp32 rounding of the sum order, and a second backward through the retained graph gives the same result again."""
+    from dp_gsat_amd.graph_index import BatchIndex
+    from dp_gsat_amd.ops import LiftedAttention, pna_aggregate
+    monkeypatch.setattr("dp_gsat_amd.graph_index._HUBS_SEEN", [False])
+    H, L = 128, 3
+    ei, batch, N = random_batch(91, 40, 1, 40)
+    ei = shuffle_edges(ei, 7)
+    g = torch.Generator().manual_seed(3)
+    xs = [torch.randn(N, H, generator=g) for _ in range(L)]
+    na = torch.rand(N, 1, generator=g)
+    gos = [torch.randn(N, 8 * H, generator=g) for _ in range(L)]
+    aggr, avg = ["mean", "min", "max", "std"], {"lin": 1.0, "log": 1.0}
+
+    def run(shared, twice=False):
+        monkeypatch.setenv("GSAT_NODE_ATT_SHARED_GRAD", "1" if shared else "0")
+        ix = BatchIndex(ei.to(dev), N)
+        ix.graphs(batch.to(dev))
+        leaf = na.to(dev).requires_grad_(True)
+        node_att = leaf * 1.0                                   # a non-leaf, as the sampler's output is
+        att = LiftedAttention(node_att, ix)
+        outs = [pna_aggregate(x.to(dev), ix, att, None, aggr, ["identity"], avg) for x in xs]
+        extra = (node_att * node_att).sum()                     # another consumer of node_att
+        torch.autograd.backward(outs + [extra], [g_.to(dev) for g_ in gos] + [None], retain_graph=twice)
+        first = leaf.grad.clone()
+        if twice:
+            leaf.grad = None
+            torch.autograd.backward(outs + [extra], [g_.to(dev) for g_ in gos] + [None])
+            assert torch.equal(first, leaf.grad)
+        return first
+
+    a, b = run(True), run(False)
+    close(a, b, 1e-6, what="d node_att: shared buffer vs per-layer buffers")
+    run(True, twice=True)
