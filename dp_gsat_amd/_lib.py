@@ -19,6 +19,7 @@ P, I64, I32, F32, SZ, INT, U64 = c_void_p, c_int64, c_int32, c_float, c_size_t, 
 # name -> (restype, argtypes); must list every symbol of include/gsat_hip.h (tests check this).
 SIGNATURES = {
     "gsat_abi_version": (INT, []),
+    "gsat_seed_next": (INT, [P, P, P]),
     "gsat_last_error": (c_char_p, []),
     "gsat_csr_workspace_bytes": (SZ, [I64, I64]),
     "gsat_rev_workspace_bytes": (SZ, [I64]),

@@ -18,6 +18,18 @@ void set_error(const char* fmt, ...) {
 }
 const char* get_error() { return g_err; }
 
+// next seed of a device-resident stream: state = (base, counter); out = splitmix64(base + counter * golden), 63 bits.  One launch per
+// seed inside a captured step (torch's graph-safe random_() costs three: the draw and two fills of its Philox offset words).
+__global__ void k_seed_next(uint64_t* __restrict__ state, uint64_t* __restrict__ out) {
+    const uint64_t c = state[1] + 1;
+    state[1] = c;
+    uint64_t z = state[0] + c * 0x9E3779B97F4A7C15ull;
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    z ^= z >> 31;
+    out[0] = z & 0x7FFFFFFFFFFFFFFFull;
+}
+
 __global__ void k_zero_words(uint32_t* __restrict__ p, size_t n) {
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) p[i] = 0u;
 }
@@ -492,6 +504,13 @@ using namespace gsat;
 extern "C" {
 
 int gsat_abi_version(void) { return GSAT_ABI_VERSION; }
+
+int gsat_seed_next(uint64_t* state, uint64_t* out, void* stream) {
+    GSAT_REQUIRE(state && out, GSAT_ERR_ARG, "gsat_seed_next: null pointer");
+    gsat::k_seed_next<<<1, 1, 0, (hipStream_t)stream>>>(state, out);
+    GSAT_LAUNCH_CHECK();
+    return GSAT_OK;
+}
 const char* gsat_last_error(void) { return gsat::get_error(); }
 
 size_t gsat_csr_workspace_bytes(int64_t E, int64_t num_rows) {

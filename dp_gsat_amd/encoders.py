@@ -92,9 +92,9 @@ class BatchNorm1d(nn.BatchNorm1d):
         seed, seed_dev = 0, None
         if p > 0.0:
             from .graph_index import sync_free
-            from .ops import new_seed
+            from .ops import device_seed, new_seed
             if sync_free():        # no host round trip inside a captured step: the seed word lives on the device
-                seed_dev = torch.empty(1, dtype=torch.int64, device=x.device).random_()
+                seed_dev = device_seed(x.device)
             else:
                 seed = new_seed()
         if sync is not None:

@@ -13,7 +13,7 @@ import torch.nn as nn
 
 from .get_model import MLP
 from .graph_index import get_index, sync_free
-from .ops import ExtractorAttention, InfoLoss, Lift, LiftedAttention, Sample, Symmetrise, edge_tensor, new_seed
+from .ops import ExtractorAttention, InfoLoss, Lift, LiftedAttention, Sample, Symmetrise, device_seed, edge_tensor, new_seed
 
 
 class ExtractorMLP(nn.Module):
@@ -71,7 +71,7 @@ class ExtractorMLP(nn.Module):
             need = self.training and ((self.mlp.dropout_p > 0 and m1 is None) or philox_noise)
             if need and sync_free():
                 # graph-capturable: the seed lives on the device and is redrawn by a graph-safe RNG op on every replay
-                seed, seed_dev = 0, torch.empty(1, dtype=torch.int64, device=emb.device).random_()
+                seed, seed_dev = 0, device_seed(emb.device)
             else:
                 seed = new_seed() if need else 0
         return ExtractorAttention.apply(emb, l1.weight, l1.bias, l2.weight, l2.bias, l3.weight, l3.bias, index, segments,

@@ -496,6 +496,27 @@ def new_seed() -> int:
     return int(torch.empty((), dtype=torch.int64).random_().item())
 
 
+_DEVICE_SEEDS = {}
+
+
+def device_seed(device) -> torch.Tensor:
+    """A fresh 1-element int64 seed tensor on ``device`` for a captured (sync-free) step: the next value of a device-resident counter stream
+    (gsat_seed_next: one launch; torch's graph-safe ``random_()`` takes three).  The stream's base comes from torch's CPU generator the first
+    time a (device, torch.initial_seed()) pair is seen, so ``torch.manual_seed`` restarts it; it must first be used outside a capture
+    (warm-up runs do), otherwise this falls back to ``random_()``."""
+    key = (str(device), torch.initial_seed())
+    st = _DEVICE_SEEDS.get(key)
+    if st is None:
+        if torch.cuda.is_current_stream_capturing() or os.environ.get("GSAT_DEVICE_SEEDS", "1") == "0":
+            return torch.empty(1, dtype=torch.int64, device=device).random_()
+        st = torch.tensor([new_seed(), 0], dtype=torch.int64, device=device)
+        _DEVICE_SEEDS.clear()
+        _DEVICE_SEEDS[key] = st
+    out = torch.empty(1, dtype=torch.int64, device=device)
+    call("gsat_seed_next", ptr(st), ptr(out), stream())
+    return out
+
+
 class Sample(torch.autograd.Function):
     """sigmoid((logits + noise)/temp): concrete (mode 1) / Gumbel (mode 2) / none (mode 0)."""
 
@@ -787,7 +808,7 @@ def relu_dropout(x, p: float, training: bool):
     if p > 0.0:
         from .graph_index import sync_free
         if sync_free():            # captured steps: the seed word lives on the device and is redrawn by a graph-safe RNG op
-            seed_dev = torch.empty(1, dtype=torch.int64, device=x.device).random_()
+            seed_dev = device_seed(x.device)
         else:
             seed = new_seed()
     return ReluDropout.apply(x, p, seed, seed_dev)

@@ -39,6 +39,11 @@ extern "C" {
 #define GSAT_ERR_BLAS (-5)         /* reserved: no entry point returns it since the library GEMMs were replaced (round 1) */
 
 int gsat_abi_version(void);
+
+/* Device-resident seed stream for captured steps: state[0] = base seed (written once by the host), state[1] = counter; every call bumps
+ * the counter and writes splitmix64(base, counter) (63 bits) to out[0], which the dropout / sampler kernels read through their seed_dev
+ * argument.  One launch; deterministic given the base seed and the number of calls. */
+int gsat_seed_next(uint64_t* state, uint64_t* out, void* stream);
 const char* gsat_last_error(void);
 
 /* =============================== integer edge bookkeeping ==================================== */
