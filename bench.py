@@ -604,9 +604,21 @@ def main():
         if distributed:
             fs.attach_dp()
         fstep = captured(fs.step) if full_graph else fs.step
-        fdt = timed(fstep, max(args.steps // 2, 3), max(args.warmup // 2, 2), dev, distributed)
         fsteps = max(args.steps // 2, 3)
-        full = dict(value=round(e_total / (fdt / fsteps) / 1e6, 3), unit="million edges/s", ms_per_step=round(fdt / fsteps * 1e3, 3),
+        fdt = timed(fstep, fsteps, max(args.warmup // 2, 2), dev, distributed)
+        by_mode = {"hipgraph" if full_graph else "eager": round(fdt / fsteps * 1e3, 3)}
+        if args.graph and not mode_given and not full_graph and not distributed:
+            # C3's whole step, default run: eager it is ~10 % faster than the replayed graph on an idle host (4.2 vs 4.8 ms) and slower on a
+            # loaded one (its ~450 launches make it host-sensitive; 5.1-5.3 ms seen).  Time the captured step too and report the faster mode;
+            # both figures stay in `ms_by_mode`.
+            G.set_sync_free(True)
+            fs2 = FullStep(wl, data, x_dim, e_dim, dev, capturable=True)
+            fdt2 = timed(captured(fs2.step), fsteps, max(args.warmup // 2, 2), dev, False)
+            by_mode["hipgraph"] = round(fdt2 / fsteps * 1e3, 3)
+            if fdt2 < fdt:
+                fdt, full_graph = fdt2, True
+            del fs2
+        full = dict(value=round(e_total / (fdt / fsteps) / 1e6, 3), unit="million edges/s", ms_per_step=round(fdt / fsteps * 1e3, 3), ms_by_mode=by_mode,
                     what="whole GSAT training step: 2 backbone passes + extractor + losses + backward + Adam (+ all-reduce)", hipgraph=full_graph,
                     gemm_precision=FWD_PRECISION[ExtractorAttention.last_forward_kind] + "; extractor backward products (da1, demb, dW1, dW2) and backbone "
                                    "Linear layers >= 2 GFLOP (forward, dx, dW): bf16x3 (split-bf16 hi*hi + hi*lo + lo*hi, fp32 accumulate, rel. error ~1e-5); "
