@@ -154,7 +154,16 @@ class FullStep:
         self.clf = G.get_model(x_dim, e_dim, num_class, False, cfg, dev)
         self.ext = G.ExtractorMLP(H, wl["edge_att"]).to(dev)
         params = list(self.clf.parameters()) + list(self.ext.parameters())
-        self.opt = torch.optim.Adam(params, lr=1e-3, weight_decay=3e-6, capturable=capturable)
+        # the reference's optimizer (torch.optim.Adam, example/trainer.py); its fused implementation is one multi-tensor kernel per step -- the
+        # default "foreach" one with capturable=True adds ~70 microsecond-sized launches per step to a captured graph (GSAT_ADAM_FUSED=0)
+        try:
+            if os.environ.get("GSAT_ADAM_FUSED", "1") == "0":
+                raise RuntimeError("fused Adam switched off")
+            self.opt = torch.optim.Adam(params, lr=1e-3, weight_decay=3e-6, capturable=capturable, fused=True)
+            self.adam = "fused"
+        except (RuntimeError, ValueError, TypeError):
+            self.opt = torch.optim.Adam(params, lr=1e-3, weight_decay=3e-6, capturable=capturable)
+            self.adam = "foreach"
         self.gsat = G.GSAT(self.clf, self.ext, G.Criterion(num_class, False), self.opt, learn_edge_att=wl["edge_att"]).train()
         self.gsat.sync_loss_dict = False
         self.flat = None
@@ -618,7 +627,7 @@ def main():
             if fdt2 < fdt:
                 fdt, full_graph = fdt2, True
             del fs2
-        full = dict(value=round(e_total / (fdt / fsteps) / 1e6, 3), unit="million edges/s", ms_per_step=round(fdt / fsteps * 1e3, 3), ms_by_mode=by_mode,
+        full = dict(value=round(e_total / (fdt / fsteps) / 1e6, 3), unit="million edges/s", ms_per_step=round(fdt / fsteps * 1e3, 3), ms_by_mode=by_mode, adam=fs.adam,
                     what="whole GSAT training step: 2 backbone passes + extractor + losses + backward + Adam (+ all-reduce)", hipgraph=full_graph,
                     gemm_precision=FWD_PRECISION[ExtractorAttention.last_forward_kind] + "; extractor backward products (da1, demb, dW1, dW2) and backbone "
                                    "Linear layers >= 2 GFLOP (forward, dx, dW): bf16x3 (split-bf16 hi*hi + hi*lo + lo*hi, fp32 accumulate, rel. error ~1e-5); "
