@@ -797,7 +797,7 @@ int gemm_splits(int64_t M, int64_t N, int64_t K, bool reduce_rows) {
     static const int target = getenv("GSAT_GEMM_SPLITK_BLOCKS") ? atoi(getenv("GSAT_GEMM_SPLITK_BLOCKS")) : 768;
     // a 64 x 64 weight gradient (GIN at H = 64) is ONE tile: with 8 slabs per split its 12 800 rows made 50 workgroups walking 8 slabs
     // each (26 us for 0.1 GFLOP); 2 slabs per split give 200 short workgroups on 64 x 64 tiles
-    const int div = div_env > 0 ? div_env : (M <= 64 && N <= 64 ? 2 : 8);
+    const int div = div_env > 0 ? div_env : (M <= 64 && N <= 64 ? 4 : 8);      // (4, not 2: the slab sum of 200 partials cost more than the shorter GEMM saved: C2 whole step 0.995 -> 0.97 ms)
     int64_t s = std::min<int64_t>(ceil_div(target, tiles), ceil_div(K, (int64_t)div * GK));
     return (int)std::max<int64_t>(1, std::min<int64_t>(s, 512));
 }
