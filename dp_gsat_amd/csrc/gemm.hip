@@ -951,6 +951,11 @@ int gemm_f32(hipStream_t stream, bool a_t, bool b_t, int64_t M, int64_t N, int64
     int tm = 2, tn = 2;
     if (splits == 1) gemm_tile(M, N, K, &tm, &tn);
     else if (!getenv("GSAT_GEMM_TILE")) { tm = M <= 64 ? 1 : 2; tn = N <= 64 ? 1 : 2; }       // split-K: do not pad a small output to 128 x 128
+    {   // split-K on the exact-fp32 kernel with fewer workgroups than 1.5 per CU (a 128 x 128 weight gradient over ~3e4 rows: ONE tile x 123
+        // splits): 64 x 64 tiles give four times the workgroups (C4: 26.9 -> ~15 us per product).  GSAT_GEMM_WGRAD_SMALL_TILES=0 switches it off
+        static const int small_tiles = getenv("GSAT_GEMM_WGRAD_SMALL_TILES") ? atoi(getenv("GSAT_GEMM_WGRAD_SMALL_TILES")) : 1;
+        if (small_tiles && splits > 1 && !split && ceil_div(M, 64 * tm) * ceil_div(N, 64 * tn) * splits < 384) tm = tn = 1;
+    }
     // split-bf16: the per-tile staging (fp32 -> hi/lo, LDS planes) is what costs, so the largest tile wins even when it leaves
     // fewer workgroups than CUs x occupancy (51 639 x 128 x 1024: 57 us at 128x128 against 69 us at 128x64)
     if (split && splits == 1 && !getenv("GSAT_GEMM_TILE")) { tm = 2; tn = N > 64 ? 2 : 1; }
