@@ -726,32 +726,38 @@ __global__ void k_slab_reduce(const float* __restrict__ slabs, int nslab, size_t
 // The same sum with four lanes per float4 of the output: lane q of a quad adds slabs q, q+4, q+8, ... (two independent partial sums, so
 // the loads pipeline), then the quad combines in a fixed tree.  4x the loads in flight and 16-byte accesses: 10.8 -> ~4 us for the
 // 128 x 32768 slabs of the extractor's weight gradients at C3.  Bitwise reproducible (the order never depends on timing).
+// P lanes share one float4 of the output (slab s goes to lane s % P): 4 for short sums, 8 from 64 slabs, 16 from 128 -- more threads in
+// flight for a kernel that is pure load latency (C3: the 202-slab sums of dW2 and dW1 in one launch, 18.5 us at P = 4, 12.8 at P = 8)
+template <int P>
 __device__ __forceinline__ void slab_reduce4_body(int64_t t, const float* __restrict__ slabs, int nslab, size_t slab_stride, int M, int N, int64_t ldc,
                                                   int accumulate, float* __restrict__ out);
+template <int P>
 __global__ void k_slab_reduce4(const float* __restrict__ slabs, int nslab, size_t slab_stride, int M, int N, int64_t ldc,
                                int accumulate, float* __restrict__ out) {
-    slab_reduce4_body((int64_t)blockIdx.x * blockDim.x + threadIdx.x, slabs, nslab, slab_stride, M, N, ldc, accumulate, out);
+    slab_reduce4_body<P>((int64_t)blockIdx.x * blockDim.x + threadIdx.x, slabs, nslab, slab_stride, M, N, ldc, accumulate, out);
 }
 // up to four pending sums in one launch: job j owns blocks [first[j], first[j + 1])
 struct SlabJobs4 { SlabJob job[4]; int first[5]; };
+template <int P>
 __global__ void k_slab_reduce_jobs(const SlabJobs4 J) {
     int j = 0;
 #pragma unroll
     for (int q = 1; q < 4; ++q) j += (int)blockIdx.x >= J.first[q] ? 1 : 0;
     const SlabJob& b = J.job[j];
-    slab_reduce4_body((int64_t)(blockIdx.x - J.first[j]) * blockDim.x + threadIdx.x, b.ws, b.nslab, b.slab, b.M, b.N, b.ldc, b.accumulate, b.out);
+    slab_reduce4_body<P>((int64_t)(blockIdx.x - J.first[j]) * blockDim.x + threadIdx.x, b.ws, b.nslab, b.slab, b.M, b.N, b.ldc, b.accumulate, b.out);
 }
+template <int P>
 __device__ __forceinline__ void slab_reduce4_body(int64_t t, const float* __restrict__ slabs, int nslab, size_t slab_stride, int M, int N, int64_t ldc,
                                                   int accumulate, float* __restrict__ out) {
-    const int q = (int)(t & 3);
-    const int64_t i4 = t >> 2;                                    // float4 index into the [M, N] output
+    const int q = (int)(t & (P - 1));
+    const int64_t i4 = t / P;                                     // float4 index into the [M, N] output
     const bool live = i4 < (int64_t)M * N / 4;
     float4 a = f4zero(), b = f4zero();
     if (live) {
         const float* p0 = slabs + i4 * 4;
         int s = q;
-        for (; s + 4 < nslab; s += 8) {
-            const float4 u = ld4(p0 + (size_t)s * slab_stride), v = ld4(p0 + (size_t)(s + 4) * slab_stride);
+        for (; s + P < nslab; s += 2 * P) {
+            const float4 u = ld4(p0 + (size_t)s * slab_stride), v = ld4(p0 + (size_t)(s + P) * slab_stride);
             a.x += u.x; a.y += u.y; a.z += u.z; a.w += u.w;
             b.x += v.x; b.y += v.y; b.z += v.z; b.w += v.w;
         }
@@ -762,7 +768,7 @@ __device__ __forceinline__ void slab_reduce4_body(int64_t t, const float* __rest
     }
     float4 r = make_float4(a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w);
 #pragma unroll
-    for (int o = 1; o <= 2; o <<= 1) {                            // (q0 + q1) + (q2 + q3), the same in every lane of the quad
+    for (int o = 1; o < P; o <<= 1) {                             // ((q0 + q1) + (q2 + q3)) + ..., the same in every lane of the group
         const float4 w = make_float4(__shfl_xor(r.x, o, 64), __shfl_xor(r.y, o, 64), __shfl_xor(r.z, o, 64), __shfl_xor(r.w, o, 64));
         const bool low = (q & o) == 0;                            // keep (lower, upper) operand order identical in both partners
         r = low ? make_float4(r.x + w.x, r.y + w.y, r.z + w.z, r.w + w.w) : make_float4(w.x + r.x, w.y + r.y, w.z + r.z, w.w + r.w);
@@ -992,8 +998,12 @@ int gemm_f32(hipStream_t stream, bool a_t, bool b_t, int64_t M, int64_t N, int64
     if (splits > 1) {
         const bool vec = N % 4 == 0 && ldc % 4 == 0 && slab % 4 == 0 && ((uintptr_t)C & 15) == 0 && ((uintptr_t)ws & 15) == 0;
         if (defer && vec) { *defer = SlabJob{ws, splits, slab, (int)M, (int)N, ldc, accumulate ? 1 : 0, C}; return GSAT_OK; }
-        if (vec)
-            k_slab_reduce4<<<(unsigned)ceil_div(M * N, 256), 256, 0, stream>>>(ws, splits, slab, (int)M, (int)N, ldc, accumulate ? 1 : 0, C);
+        if (vec && splits >= 128)
+            k_slab_reduce4<16><<<(unsigned)ceil_div(M * N * 4, 256), 256, 0, stream>>>(ws, splits, slab, (int)M, (int)N, ldc, accumulate ? 1 : 0, C);
+        else if (vec && splits >= 64)
+            k_slab_reduce4<8><<<(unsigned)ceil_div(M * N * 2, 256), 256, 0, stream>>>(ws, splits, slab, (int)M, (int)N, ldc, accumulate ? 1 : 0, C);
+        else if (vec)
+            k_slab_reduce4<4><<<(unsigned)ceil_div(M * N, 256), 256, 0, stream>>>(ws, splits, slab, (int)M, (int)N, ldc, accumulate ? 1 : 0, C);
         else
             k_slab_reduce<<<(unsigned)ceil_div(M * N, 256), 256, 0, stream>>>(ws, splits, slab, (int)M, (int)N, ldc, accumulate ? 1 : 0, C);
         GSAT_LAUNCH_CHECK();
@@ -1003,18 +1013,21 @@ int gemm_f32(hipStream_t stream, bool a_t, bool b_t, int64_t M, int64_t N, int64
 
 int slab_reduce_jobs(hipStream_t stream, const SlabJob* jobs, int n) {
     SlabJobs4 J{};
-    int m = 0, blocks = 0;
+    int m = 0, blocks = 0, wide = 0;
+    for (int i = 0; i < n; ++i) wide = std::max(wide, jobs[i].nslab >= 128 ? 4 : (jobs[i].nslab >= 64 ? 2 : 0));
     for (int i = 0; i < n; ++i) {
         if (jobs[i].nslab <= 0) continue;
         GSAT_REQUIRE(m < 4, GSAT_ERR_ARG, "slab_reduce_jobs: more than four pending sums");
         J.job[m] = jobs[i];
         J.first[m] = blocks;
-        blocks += (int)ceil_div((int64_t)jobs[i].M * jobs[i].N, 256);
+        blocks += (int)ceil_div((int64_t)jobs[i].M * jobs[i].N * (wide ? wide : 1), 256);
         ++m;
     }
     for (int q = m; q <= 4; ++q) J.first[q] = blocks;
     if (!blocks) return GSAT_OK;
-    k_slab_reduce_jobs<<<blocks, 256, 0, stream>>>(J);
+    if (wide == 4) k_slab_reduce_jobs<16><<<blocks, 256, 0, stream>>>(J);
+    else if (wide == 2) k_slab_reduce_jobs<8><<<blocks, 256, 0, stream>>>(J);
+    else k_slab_reduce_jobs<4><<<blocks, 256, 0, stream>>>(J);
     GSAT_LAUNCH_CHECK();
     return GSAT_OK;
 }
@@ -1060,7 +1073,7 @@ int pna_post_dw(hipStream_t stream, const PnaVirt& pv, int64_t Nrows, const floa
 #undef GO
     GSAT_LAUNCH_CHECK();
     if (splits > 1) {
-        k_slab_reduce4<<<(unsigned)ceil_div(Ho * Kc, 256), 256, 0, stream>>>(ws, splits, slab, (int)Ho, (int)Kc, lddw, 0, dW);
+        k_slab_reduce4<4><<<(unsigned)ceil_div(Ho * Kc, 256), 256, 0, stream>>>(ws, splits, slab, (int)Ho, (int)Kc, lddw, 0, dW);
         GSAT_LAUNCH_CHECK();
     }
     return GSAT_OK;
